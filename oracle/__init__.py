@@ -1,0 +1,301 @@
+"""ctypes front-end of the CPU oracle (oracle/drt_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importers allowed: tests/, __graft_entry__.smoke(),
+bench.py's cpu_baseline leg.  dustraytracer_amd/ must never import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdrt_oracle.so")
+_lib = None
+
+NODE_DTYPE = np.dtype([("is_leaf", "<i4"), ("bmin", "<f4", 3), ("bmax", "<f4", 3), ("child1", "<i4"),
+                       ("child2", "<i4"), ("prim_count", "<i4"), ("prim_start", "<i4")])
+TRI_DTYPE = np.dtype([("centroid", "<f4", 3), ("p", "<f4", (3, 3)), ("n", "<f4", (3, 3)),
+                      ("uv", "<f4", (3, 2)), ("face_n", "<f4", 3), ("material", "<i4")])
+MAT_DTYPE = np.dtype([("albedo", "<f4", 3), ("albedo_tex", "<i4")])
+assert NODE_DTYPE.itemsize == 44 and TRI_DTYPE.itemsize == 124 and MAT_DTYPE.itemsize == 16
+
+
+class Texture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("comps", C.c_int32), ("_pad", C.c_int32),
+                ("data", C.c_void_p)]
+
+
+class Settings(C.Structure):
+    _fields_ = [("gamma_correction", C.c_int32), ("tone_mapping", C.c_int32), ("enable_sunlight", C.c_int32),
+                ("max_samples", C.c_int32), ("ray_bounce_limit", C.c_int32), ("render_mode", C.c_int32),
+                ("debug_mode", C.c_int32), ("sunlight_dir", C.c_float * 2), ("sunlight_color", C.c_float * 3),
+                ("sunlight_intensity", C.c_float), ("sky_color", C.c_float * 3), ("sky_intensity", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("exposure", C.c_float), ("vfov_rad", C.c_float), ("defocus_angle", C.c_float),
+                ("focus_dist", C.c_float), ("position", C.c_float * 3), ("forward", C.c_float * 3)]
+
+
+class SceneC(C.Structure):
+    _fields_ = [("tris", C.c_void_p), ("n_tris", C.c_int32), ("nodes", C.c_void_p), ("n_nodes", C.c_int32),
+                ("mats", C.c_void_p), ("n_mats", C.c_int32), ("texs", C.c_void_p), ("n_texs", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "samples", "rays", "node_visits", "inner_visits", "tri_tests", "hits_textured", "hits_flat",
+        "shadow_rays", "inner_visits_shadow", "tri_tests_shadow", "anyhit_alpha", "sphere_iters", "max_stack")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+    def algorithmic_bytes(self):
+        """B = 40/sample + 56/interior visit + 36/triangle test + 60|32/shaded hit (+ shadow terms)."""
+        return (40 * self.samples + 56 * self.inner_visits + 36 * self.tri_tests + 60 * self.hits_textured
+                + 32 * self.hits_flat + 56 * self.inner_visits_shadow + 36 * self.tri_tests_shadow)
+
+
+def build(force=False):
+    """Compile oracle/drt_oracle.c -> oracle/libdrt_oracle.so (gcc, IEEE, no contraction)."""
+    src = os.path.join(_HERE, "drt_oracle.c")
+    hdr = os.path.join(_HERE, "drt_oracle.h")
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        return _LIB_PATH
+    cmd = ["gcc", "-O2", "-std=gnu99", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-pthread",
+           "-Wall", "-o", _LIB_PATH, src, "-lm"]
+    subprocess.run(cmd, check=True, cwd=_HERE)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.o_pcg_hash.restype = C.c_uint32
+        L.o_pcg_hash.argtypes = [C.c_uint32]
+        L.o_bvh_build.restype = C.c_int32
+        L.o_bvh_build.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
+        L.o_build_triangles.restype = None
+        L.o_build_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        L.o_render.restype = None
+        L.o_render.argtypes = [C.POINTER(SceneC), C.POINTER(Camera), C.POINTER(Settings), C.c_int32, C.c_int32,
+                               C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                               C.c_int32, C.POINTER(Counters)]
+        L.o_default_settings.argtypes = [C.POINTER(Settings)]
+        L.o_default_camera.argtypes = [C.POINTER(Camera)]
+        _lib = L
+    return _lib
+
+
+def default_settings(**kw):
+    s = Settings()
+    lib().o_default_settings(C.byref(s))
+    for k, v in kw.items():
+        _set(s, k, v)
+    return s
+
+
+def default_camera(**kw):
+    c = Camera()
+    lib().o_default_camera(C.byref(c))
+    for k, v in kw.items():
+        _set(c, k, v)
+    return c
+
+
+def _set(struct, key, value):
+    cur = getattr(struct, key)
+    if hasattr(cur, "__len__"):
+        for i, v in enumerate(value):
+            cur[i] = v
+    else:
+        setattr(struct, key, value)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Scene:
+    """Triangles + BVH + materials + textures held as numpy arrays for the C oracle."""
+
+    def __init__(self, tris, materials, textures):
+        self.tris = np.ascontiguousarray(tris, dtype=TRI_DTYPE)
+        self.nodes = np.zeros(0, NODE_DTYPE)
+        self.mats = np.zeros(max(len(materials), 1), MAT_DTYPE)
+        for i, (alb, tex) in enumerate(materials):
+            self.mats[i]["albedo"] = alb
+            self.mats[i]["albedo_tex"] = tex
+        self.n_mats = len(materials)
+        self.textures = textures                       # list of HxWxC uint8
+        self._tex_padded = []
+        self._tex_c = (Texture * max(len(textures), 1))()
+        for i, t in enumerate(textures):
+            h, w, c = t.shape
+            padded = np.zeros((h * w + w + 1) * c, np.uint8)    # defined bytes for the latent OOB texel
+            padded[: h * w * c] = t.reshape(-1)
+            self._tex_padded.append(padded)
+            self._tex_c[i].width, self._tex_c[i].height, self._tex_c[i].comps = w, h, c
+            self._tex_c[i].data = padded.ctypes.data
+
+    @classmethod
+    def load_glb(cls, path):
+        from .gltf_flatten import flatten
+        d = flatten(path)
+        n = len(d["mat"])
+        tris = np.zeros(n, TRI_DTYPE)
+        lib().o_build_triangles(_ptr(d["pos"]), _ptr(d["nrm"]), _ptr(d["uv"]),
+                                _ptr(np.ascontiguousarray(d["mat"], np.int32)), n, _ptr(tris))
+        sc = cls(tris, d["materials"], d["textures"])
+        sc.meshes = d["meshes"]
+        return sc
+
+    def build_bvh(self, leaf=20, bins=8):
+        """BVHBuilder{m_TargetLeafPrimitivesCount=leaf, m_BinCount=bins}.buildIterative (EditorLayer.cpp:52-55)."""
+        cap = 2 * len(self.tris) + 2
+        nodes = np.zeros(cap, NODE_DTYPE)
+        n = lib().o_bvh_build(_ptr(self.tris), len(self.tris), leaf, bins, _ptr(nodes), cap)
+        if n < 0:
+            raise RuntimeError("o_bvh_build failed: %d" % n)
+        self.nodes = nodes[:n].copy()
+        return self
+
+    def c_scene(self):
+        s = SceneC()
+        s.tris, s.n_tris = self.tris.ctypes.data, len(self.tris)
+        s.nodes, s.n_nodes = self.nodes.ctypes.data, len(self.nodes)
+        s.mats, s.n_mats = self.mats.ctypes.data, self.n_mats
+        s.texs, s.n_texs = C.addressof(self._tex_c), len(self.textures)
+        return s
+
+
+def render(scene, cam, settings, W, H, frame_first=1, n_frames=1, accum=None, threads=None,
+           stripe_rows=1, rank=0, world=1, want_counters=False):
+    """Returns (rgba[H,W,4] f32, accum[H,W,3] f32, Counters|None). Frame indices start at 1."""
+    if threads is None:
+        threads = os.cpu_count() or 1
+    if accum is None:
+        accum = np.zeros((H, W, 3), np.float32)
+    accum = np.ascontiguousarray(accum, np.float32)
+    rgba = np.zeros((H, W, 4), np.float32)
+    cnt = Counters() if want_counters else None
+    cs = scene.c_scene()
+    lib().o_render(C.byref(cs), C.byref(cam), C.byref(settings), W, H, frame_first, n_frames, _ptr(accum), _ptr(rgba),
+                   threads, stripe_rows, rank, world, C.byref(cnt) if cnt is not None else None)
+    return rgba, accum, cnt
+
+
+def tree_depth(nodes):
+    """Depth (levels) of the BVH rooted at the last node."""
+    if len(nodes) == 0:
+        return 0
+    depth, stack = 0, [(len(nodes) - 1, 1)]
+    while stack:
+        i, d = stack.pop()
+        depth = max(depth, d)
+        if not nodes[i]["is_leaf"]:
+            stack.append((int(nodes[i]["child1"]), d + 1))
+            stack.append((int(nodes[i]["child2"]), d + 1))
+    return depth
+
+
+# ---- known-answer-test wrappers around the leaf functions (o_kat_*) ----
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, np.uint32)
+
+
+def kat_pcg(values):
+    L = lib()
+    return np.array([L.o_pcg_hash(int(v)) for v in np.asarray(values).ravel()], np.uint32)
+
+
+def kat_randfloat(seed, n):
+    out = np.zeros(n, np.float32)
+    end = C.c_uint32(0)
+    lib().o_kat_random_float(C.c_uint32(seed), C.c_int32(n), _ptr(out), C.byref(end))
+    return out, int(end.value)
+
+
+def _kat_vec(fn, seeds, width, with_iters=False):
+    seeds = _u32(seeds)
+    n = len(seeds)
+    out = np.zeros((n, width), np.float32)
+    so = np.zeros(n, np.uint32)
+    if with_iters:
+        it = np.zeros(n, np.int32)
+        fn(_ptr(seeds), C.c_int32(n), _ptr(out), _ptr(so), _ptr(it))
+        return out, so, it
+    fn(_ptr(seeds), C.c_int32(n), _ptr(out), _ptr(so))
+    return out, so
+
+
+def kat_unitvec(seeds):
+    return _kat_vec(lib().o_kat_unit_vec3, seeds, 3)
+
+
+def kat_unitsphere(seeds):
+    return _kat_vec(lib().o_kat_unit_sphere, seeds, 3, with_iters=True)
+
+
+def kat_unitdisk(seeds):
+    return _kat_vec(lib().o_kat_unit_disk, seeds, 2)
+
+
+def kat_slab(rays6, boxes6):
+    rays6, boxes6 = _f32(rays6), _f32(boxes6)
+    out = np.zeros(len(rays6), np.float32)
+    lib().o_kat_slab(_ptr(rays6), _ptr(boxes6), C.c_int32(len(rays6)), _ptr(out))
+    return out
+
+
+def kat_intersect(rays6, tris9):
+    rays6, tris9 = _f32(rays6), _f32(tris9)
+    n = len(rays6)
+    out = np.zeros((n, 4), np.float32)
+    hit = np.zeros(n, np.int32)
+    lib().o_kat_intersect(_ptr(rays6), _ptr(tris9), C.c_int32(n), _ptr(out), _ptr(hit))
+    return out, hit
+
+
+def kat_getray(cam, width, height, uv2, seeds):
+    uv2, seeds = _f32(uv2), _u32(seeds)
+    n = len(seeds)
+    out = np.zeros((n, 6), np.float32)
+    so = np.zeros(n, np.uint32)
+    lib().o_kat_get_ray(C.byref(cam), _ptr(uv2), _ptr(seeds), C.c_int32(n), C.c_float(width), C.c_float(height),
+                        _ptr(out), _ptr(so))
+    return out, so
+
+
+def _kat_texture(texels):
+    h, w, c = texels.shape
+    padded = np.zeros((h * w + w + 1) * c, np.uint8)
+    padded[: h * w * c] = texels.reshape(-1)
+    t = Texture()
+    t.width, t.height, t.comps, t.data = w, h, c, padded.ctypes.data
+    return t, padded
+
+
+def kat_texpixel(texels, uv2):
+    t, keep = _kat_texture(texels)
+    uv2 = _f32(uv2)
+    out = np.zeros((len(uv2), 3), np.float32)
+    lib().o_kat_tex_pixel(C.byref(t), _ptr(uv2), C.c_int32(len(uv2)), _ptr(out))
+    return out
+
+
+def kat_texalpha(texels, uv2):
+    t, keep = _kat_texture(texels)
+    uv2 = _f32(uv2)
+    out = np.zeros(len(uv2), np.float32)
+    lib().o_kat_tex_alpha(C.byref(t), _ptr(uv2), C.c_int32(len(uv2)), _ptr(out))
+    return out

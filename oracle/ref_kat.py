@@ -1,0 +1,94 @@
+"""Python side of oracle/_ref/ref_kat (the reference's own leaf functions).
+
+TEST INFRASTRUCTURE ONLY.  Used by tests/ and by tests/golden/make_kat_golden.py.
+"""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REF_KAT = os.path.join(_HERE, "_ref", "ref_kat")
+
+
+def available():
+    return os.path.isfile(REF_KAT) and os.access(REF_KAT, os.X_OK)
+
+
+def _run(fn, payload):
+    with tempfile.TemporaryDirectory() as d:
+        fi, fo = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fi, "wb") as f:
+            f.write(payload)
+        subprocess.run([REF_KAT, fn, fi, fo], check=True)
+        with open(fo, "rb") as f:
+            return f.read()
+
+
+def pcg(values):
+    return np.frombuffer(_run("pcg", np.asarray(values, "<u4").tobytes()), "<u4").copy()
+
+
+def randfloat(seed, n):
+    raw = _run("randfloat", np.array([seed, n], "<u4").tobytes())
+    return np.frombuffer(raw[: 4 * n], "<f4").copy(), int(np.frombuffer(raw[4 * n:], "<u4")[0])
+
+
+def _vec_seed(fn, seeds, width):
+    rec = np.dtype([("v", "<f4", width), ("seed", "<u4")])
+    out = np.frombuffer(_run(fn, np.asarray(seeds, "<u4").tobytes()), rec)
+    return out["v"].copy(), out["seed"].copy()
+
+
+def unitvec(seeds):
+    return _vec_seed("unitvec", seeds, 3)
+
+
+def unitsphere(seeds):
+    return _vec_seed("unitsphere", seeds, 3)
+
+
+def unitdisk(seeds):
+    return _vec_seed("unitdisk", seeds, 2)
+
+
+def slab(rays6, boxes6):
+    data = np.concatenate([np.asarray(rays6, "<f4").reshape(-1, 6), np.asarray(boxes6, "<f4").reshape(-1, 6)], axis=1)
+    return np.frombuffer(_run("slab", np.ascontiguousarray(data).tobytes()), "<f4").copy()
+
+
+def intersect(rays6, tris9):
+    data = np.concatenate([np.asarray(rays6, "<f4").reshape(-1, 6), np.asarray(tris9, "<f4").reshape(-1, 9)], axis=1)
+    rec = np.dtype([("tuvw", "<f4", 4), ("hit", "<i4")])
+    out = np.frombuffer(_run("intersect", np.ascontiguousarray(data).tobytes()), rec)
+    return out["tuvw"].copy(), out["hit"].copy()
+
+
+def getray(cam, width, height, uv2, seeds):
+    """cam = (exposure, vfov_rad, defocus_angle, focus_dist, pos3, fwd3)"""
+    head = np.array([cam[0], cam[1], cam[2], cam[3], *cam[4], *cam[5], width, height], "<f4")
+    rec = np.dtype([("uv", "<f4", 2), ("seed", "<u4")])
+    body = np.zeros(len(seeds), rec)
+    body["uv"] = np.asarray(uv2, "<f4").reshape(-1, 2)
+    body["seed"] = np.asarray(seeds, "<u4")
+    orec = np.dtype([("ray", "<f4", 6), ("seed", "<u4")])
+    out = np.frombuffer(_run("getray", head.tobytes() + body.tobytes()), orec)
+    return out["ray"].copy(), out["seed"].copy()
+
+
+def _tex(fn, texels, uv2):
+    h, w, c = texels.shape
+    uv = np.asarray(uv2, "<f4").reshape(-1, 2)
+    padded = np.zeros((h * w + w + 1) * c, np.uint8)
+    padded[: h * w * c] = texels.reshape(-1)
+    payload = np.array([w, h, c, len(uv)], "<i4").tobytes() + uv.tobytes() + padded.tobytes()
+    return np.frombuffer(_run(fn, payload), "<f4").copy()
+
+
+def texpixel(texels, uv2):
+    return _tex("texpixel", texels, uv2).reshape(-1, 3)
+
+
+def texalpha(texels, uv2):
+    return _tex("texalpha", texels, uv2)

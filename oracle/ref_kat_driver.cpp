@@ -1,0 +1,129 @@
+// ref_kat_driver.cpp -- known-answer-test driver around the REFERENCE's own leaf functions.
+//
+// TEST INFRASTRUCTURE ONLY.  This file is ours; everything it calls is compiled
+// straight from /root/reference/DustRayTracer/src (see oracle/Makefile, target
+// _ref/ref_kat): Core/Bounds.cu, Core/CudaMath/Random.cu,
+// Core/Kernel/Shaders/Intersection.cu, Core/Scene/Camera.cu,
+// Core/Scene/Texture.cu, Core/Interval.cu.  Headers come from the image: the
+// CUDA toolkit headers bundled with triton, glm and stb_image vendored by the
+// reference.  No stand-in headers or libraries are written; the few CUDA runtime
+// symbols referenced by code paths we never call stay unresolved.
+//
+// usage: ref_kat <function> <in.bin> <out.bin>     (raw little-endian arrays)
+#include "Core/Bounds.cuh"
+#include "Core/Ray.cuh"
+#include "Core/CudaMath/Random.cuh"
+#include "Core/Kernel/Shaders/Intersection.cuh"
+#include "Core/Scene/Camera.cuh"
+#include "Core/Scene/Texture.cuh"
+#include "Core/Scene/Triangle.cuh"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static std::vector<unsigned char> slurp(const char *path)
+{
+    std::vector<unsigned char> v;
+    FILE *f = fopen(path, "rb");
+    if (!f) { perror(path); exit(2); }
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    v.resize((size_t)n);
+    if (n && fread(v.data(), 1, (size_t)n, f) != (size_t)n) { perror("read"); exit(2); }
+    fclose(f);
+    return v;
+}
+
+struct Out {
+    std::vector<unsigned char> b;
+    template <class T> void put(const T &v) { const unsigned char *p = (const unsigned char *)&v; b.insert(b.end(), p, p + sizeof(T)); }
+    void put3(float3 v) { put(v.x); put(v.y); put(v.z); }
+};
+
+// Same layout as Core/Scene/Texture.cuh:14-19 (d_data is private; the only
+// constructors need the CUDA runtime, so the object is filled bytewise).
+struct TextureBits { const char *name; int width, height; int componentCount; unsigned char *d_data; };
+static_assert(sizeof(TextureBits) == sizeof(Texture), "Texture layout");
+
+int main(int argc, char **argv)
+{
+    if (argc != 4) { fprintf(stderr, "usage: %s <function> <in.bin> <out.bin>\n", argv[0]); return 2; }
+    std::string fn = argv[1];
+    std::vector<unsigned char> in = slurp(argv[2]);
+    Out out;
+    const float *fin = (const float *)in.data();
+    const uint32_t *uin = (const uint32_t *)in.data();
+
+    if (fn == "pcg") {                                   // in: u32[n] -> out: u32[n]
+        for (size_t i = 0; i < in.size() / 4; i++) out.put((uint32_t)pcg_hash(uin[i]));
+    } else if (fn == "randfloat") {                      // in: u32 seed, u32 n -> out: f32[n], u32 seed
+        uint32_t seed = uin[0], n = uin[1];
+        for (uint32_t i = 0; i < n; i++) out.put(randomFloat(seed));
+        out.put(seed);
+    } else if (fn == "unitvec" || fn == "unitsphere") {  // in: u32[n] -> out: n x (f32[3], u32 seed)
+        for (size_t i = 0; i < in.size() / 4; i++) {
+            uint32_t seed = uin[i];
+            float3 v = fn == "unitvec" ? randomUnitVec3(seed) : randomUnitSphereVec3(seed);
+            out.put3(v); out.put(seed);
+        }
+    } else if (fn == "unitdisk") {                       // in: u32[n] -> out: n x (f32[2], u32 seed)
+        for (size_t i = 0; i < in.size() / 4; i++) {
+            uint32_t seed = uin[i];
+            float2 v = random_in_unit_disk(seed);
+            out.put(v.x); out.put(v.y); out.put(seed);
+        }
+    } else if (fn == "slab") {                           // in: n x (orig3, dir3, min3, max3) -> out: f32[n]
+        for (size_t i = 0; i + 12 <= in.size() / 4; i += 12) {
+            Ray r(make_float3(fin[i], fin[i + 1], fin[i + 2]), make_float3(fin[i + 3], fin[i + 4], fin[i + 5]));
+            Bounds3f b(make_float3(fin[i + 6], fin[i + 7], fin[i + 8]), make_float3(fin[i + 9], fin[i + 10], fin[i + 11]));
+            out.put(b.intersect(r));
+        }
+    } else if (fn == "intersect") {                      // in: n x (orig3, dir3, v0, v1, v2) -> out: n x (t, U, V, W, i32 hit)
+        for (size_t i = 0; i + 15 <= in.size() / 4; i += 15) {
+            Ray r(make_float3(fin[i], fin[i + 1], fin[i + 2]), make_float3(fin[i + 3], fin[i + 4], fin[i + 5]));
+            Triangle t;
+            t.vertex0.position = make_float3(fin[i + 6], fin[i + 7], fin[i + 8]);
+            t.vertex1.position = make_float3(fin[i + 9], fin[i + 10], fin[i + 11]);
+            t.vertex2.position = make_float3(fin[i + 12], fin[i + 13], fin[i + 14]);
+            ShortHitPayload p = Intersection(r, &t);
+            int32_t hit = p.primitiveptr != nullptr;
+            out.put(p.hit_distance);
+            // UVW is left uninitialised by the reference on a miss
+            out.put(hit ? p.UVW.x : 0.f); out.put(hit ? p.UVW.y : 0.f); out.put(hit ? p.UVW.z : 0.f);
+            out.put(hit);
+        }
+    } else if (fn == "getray") {
+        // in: exposure, vfov_rad, defocus_angle, focus_dist, pos3, fwd3, width, height, then n x (u, v, u32 seed)
+        Camera cam(make_float3(fin[4], fin[5], fin[6]));
+        cam.exposure = fin[0]; cam.vfov_rad = fin[1]; cam.defocus_angle = fin[2]; cam.focus_dist = fin[3];
+        cam.m_Forward_dir = make_float3(fin[7], fin[8], fin[9]);
+        float width = fin[10], height = fin[11];
+        for (size_t i = 12; i + 3 <= in.size() / 4; i += 3) {
+            uint32_t seed = uin[i + 2];
+            Ray r = cam.GetRay(make_float2(fin[i], fin[i + 1]), width, height, seed);
+            out.put3(r.getOrigin()); out.put3(r.getDirection()); out.put(seed);
+        }
+    } else if (fn == "texpixel" || fn == "texalpha") {
+        // in: i32 w, h, comps, n; n x (u, v); then texel bytes (padded by the caller)
+        const int32_t *iin = (const int32_t *)in.data();
+        int w = iin[0], h = iin[1], c = iin[2], n = iin[3];
+        TextureBits bits = { "kat", w, h, c, in.data() + 16 + (size_t)n * 8 };
+        Texture tex;
+        memcpy((void *)&tex, &bits, sizeof bits);
+        const float *uv = fin + 4;
+        for (int i = 0; i < n; i++) {
+            float2 q = make_float2(uv[2 * i], uv[2 * i + 1]);
+            if (fn == "texpixel") out.put3(tex.getPixel(q)); else out.put(tex.getAlpha(q));
+        }
+    } else {
+        fprintf(stderr, "unknown function %s\n", fn.c_str());
+        return 2;
+    }
+
+    FILE *f = fopen(argv[3], "wb");
+    if (!f) { perror(argv[3]); return 2; }
+    if (!out.b.empty()) fwrite(out.b.data(), 1, out.b.size(), f);
+    fclose(f);
+    return 0;
+}
