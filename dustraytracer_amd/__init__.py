@@ -1,0 +1,380 @@
+"""dustraytracer_amd -- MI355X-native path-tracing core behind DustRayTracer's Renderer/Scene API.
+
+Python host-side mirror of the reference's classes over the C ABI of include/drt.h
+(dustraytracer_amd/libdrt_hip.so, hand-written HIP for gfx950).  Names follow the reference:
+
+    Scene.loadGLTFmodel            Core/Scene/Scene.cuh:41-57
+    BVHBuilder.buildIterative      Core/BVH/BVHBuilder.cuh:12-23
+    Camera                         Core/Scene/Camera.cuh:14-48
+    RendererSettings               Core/Scene/RendererSettings.h:4-35
+    Renderer.ResizeBuffer/Render/resetAccumulationBuffer/getSampleCount   Core/Renderer.hpp:14-47
+
+There is no CPU fallback: importing works anywhere the shared library loads, but creating a Renderer
+without a GPU raises DrtError.  A missing shared library raises ImportError (build it with
+`python -c "import __graft_entry__ as g; g.build()"` or `make -C dustraytracer_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdrt_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError("dustraytracer_amd: %s is missing -- the HIP extension must be built "
+                      "(make -C dustraytracer_amd/csrc); there is no fallback path" % LIB_PATH)
+_lib = C.CDLL(LIB_PATH)
+
+
+class DrtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("drt error %d: %s" % (code, message))
+        self.code = code
+
+
+OK, ERR_INVALID, ERR_IO, ERR_PARSE, ERR_UNSUPPORTED, ERR_DEVICE, ERR_BVH = 0, -1, -2, -3, -4, -5, -6
+
+
+class RendererSettings(C.Structure):
+    """Core/Scene/RendererSettings.h:4-35"""
+    NORMALMODE, DEBUGMODE = 0, 1
+    ALBEDO_DEBUG, NORMAL_DEBUG, BARYCENTRIC_DEBUG, UVS_DEBUG, MESHBVH_DEBUG, WORLDBVH_DEBUG = range(6)
+    _fields_ = [("gamma_correction", C.c_int32), ("tone_mapping", C.c_int32), ("enableSunlight", C.c_int32),
+                ("max_samples", C.c_int32), ("ray_bounce_limit", C.c_int32), ("RenderMode", C.c_int32),
+                ("DebugMode", C.c_int32), ("sunlight_dir", C.c_float * 2), ("sunlight_color", C.c_float * 3),
+                ("sunlight_intensity", C.c_float), ("sky_color", C.c_float * 3), ("sky_intensity", C.c_float)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        _lib.drt_default_settings(C.byref(self))
+        for k, v in kw.items():
+            _assign(self, k, v)
+
+
+class _CameraPOD(C.Structure):
+    _fields_ = [("exposure", C.c_float), ("vfov_rad", C.c_float), ("defocus_angle", C.c_float),
+                ("focus_dist", C.c_float), ("position", C.c_float * 3), ("forward", C.c_float * 3)]
+
+
+class Camera:
+    """Core/Scene/Camera.cuh:14-48 (public fields + OnUpdate/Rotate/GetPosition)."""
+
+    def __init__(self, pos=(0.0, 2.0, 5.0)):
+        pod = _CameraPOD()
+        _lib.drt_default_camera(C.byref(pod))
+        self.exposure, self.vfov_rad = pod.exposure, pod.vfov_rad
+        self.defocus_angle, self.focus_dist = pod.defocus_angle, pod.focus_dist
+        self.m_movement_speed = 10.0
+        self.m_Position = np.array(pos, np.float32)
+        self.m_Forward_dir = np.array([0, 0, -1], np.float32)
+        self.m_Up_dir = np.array([0, 1, 0], np.float32)
+        self.m_Right_dir = np.cross(self.m_Forward_dir, self.m_Up_dir).astype(np.float32)
+
+    def GetPosition(self):
+        return self.m_Position.copy()
+
+    def OnUpdate(self, velocity, delta):
+        """Camera.cu:44-58: move along the camera basis."""
+        basis = np.stack([self.m_Right_dir, self.m_Up_dir, self.m_Forward_dir], axis=1).astype(np.float32)
+        move = basis @ np.asarray(velocity, np.float32)
+        self.m_Position = (self.m_Position + np.float32(self.m_movement_speed) * move * np.float32(delta)).astype(np.float32)
+
+    def Rotate(self, delta):
+        """Camera.cu:61-80: delta = (sin_x, cos_x, sin_y, cos_y)."""
+        sx, cx, sy, cy = (np.float32(v) for v in delta)
+        f, up = self.m_Forward_dir, self.m_Up_dir
+        f = f * cx + np.cross(up, f) * sx + up * np.dot(up, f) * (1 - cx)
+        r = self.m_Right_dir
+        f = f * cy + np.cross(r, f) * sy + r * np.dot(r, f) * (1 - cy)
+        self.m_Forward_dir = f.astype(np.float32)
+        self.m_Right_dir = np.cross(self.m_Forward_dir, up).astype(np.float32)
+
+    def _pod(self):
+        pod = _CameraPOD()
+        pod.exposure, pod.vfov_rad = self.exposure, self.vfov_rad
+        pod.defocus_angle, pod.focus_dist = self.defocus_angle, self.focus_dist
+        for i in range(3):
+            pod.position[i] = float(self.m_Position[i])
+            pod.forward[i] = float(self.m_Forward_dir[i])
+        return pod
+
+
+TRIANGLE_DTYPE = np.dtype({"names": ["centroid", "vertex", "face_normal", "material"],
+                           "formats": [("<f4", 3), (np.dtype([("position", "<f4", 3), ("normal", "<f4", 3), ("uv", "<f4", 2)]), 3),
+                                       ("<f4", 3), "<i4"],
+                           "offsets": [0, 16, 112, 124], "itemsize": 128})
+NODE_DTYPE = np.dtype({"names": ["is_leaf", "bmin", "bmax", "child1", "child2", "prim_count", "prim_start"],
+                       "formats": ["u1", ("<f4", 3), ("<f4", 3), "<i4", "<i4", "<i4", "<i4"],
+                       "offsets": [0, 4, 16, 28, 32, 36, 40], "itemsize": 44})
+MATERIAL_DTYPE = np.dtype({"names": ["albedo", "emissive", "albedo_tex", "roughness", "transmission", "refractive_index", "metallic"],
+                           "formats": [("<f4", 3), ("<f4", 3), "<i4", "<f4", "u1", "<f4", "u1"],
+                           "offsets": [0, 12, 24, 28, 32, 36, 40], "itemsize": 44})
+MESH_DTYPE = np.dtype([("primitives_offset", "<i4"), ("tris_count", "<i4")])
+
+
+class _TexInfo(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("components", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "node_visits", "inner_visits", "tri_tests",
+                                           "hits_textured", "hits_flat", "shadow_rays", "inner_visits_shadow",
+                                           "tri_tests_shadow")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+    def algorithmic_bytes(self):
+        """40 B/sample + 56 B/interior visit + 36 B/triangle test + 60|32 B/shaded hit (+ shadow terms)."""
+        return (40 * self.samples + 56 * self.inner_visits + 36 * self.tri_tests + 60 * self.hits_textured
+                + 32 * self.hits_flat + 56 * self.inner_visits_shadow + 36 * self.tri_tests_shadow)
+
+
+def _sig(name, restype, *argtypes):
+    fn = getattr(_lib, name)          # AttributeError here = the library does not export what drt.h declares
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+_P = C.c_void_p
+_sig("drt_abi_version", C.c_int)
+_sig("drt_last_error", C.c_char_p)
+_sig("drt_device_count", C.c_int)
+_sig("drt_default_settings", None, C.POINTER(RendererSettings))
+_sig("drt_default_camera", None, C.POINTER(_CameraPOD))
+_sig("drt_scene_create", _P)
+_sig("drt_scene_destroy", None, _P)
+_sig("drt_scene_load_gltf", C.c_int, _P, C.c_char_p)
+_sig("drt_scene_set_geometry", C.c_int, _P, _P, _P, _P, _P, C.c_int32)
+_sig("drt_scene_add_material", C.c_int, _P, C.POINTER(C.c_float), C.c_int32)
+_sig("drt_scene_add_texture", C.c_int, _P, _P, C.c_int32, C.c_int32, C.c_int32)
+_sig("drt_scene_build_bvh", C.c_int, _P, C.c_int32, C.c_int32)
+for _n in ("triangle", "node", "material", "texture", "mesh"):
+    _sig("drt_scene_%s_count" % _n, C.c_int32, _P)
+_sig("drt_scene_bvh_depth", C.c_int32, _P)
+for _n in ("triangles", "nodes", "materials", "meshes"):
+    _sig("drt_scene_get_%s" % _n, C.c_int, _P, _P, C.c_int32)
+_sig("drt_scene_get_texture_info", C.c_int, _P, C.c_int32, C.POINTER(_TexInfo))
+_sig("drt_scene_get_texture_texels", C.c_int, _P, C.c_int32, _P, C.c_size_t)
+_sig("drt_renderer_create", _P, C.c_int32)
+_sig("drt_renderer_destroy", None, _P)
+_sig("drt_renderer_resize", C.c_int, _P, C.c_uint32, C.c_uint32)
+_sig("drt_renderer_set_settings", C.c_int, _P, C.POINTER(RendererSettings))
+_sig("drt_renderer_get_settings", C.c_int, _P, C.POINTER(RendererSettings))
+_sig("drt_renderer_render", C.c_int, _P, C.POINTER(_CameraPOD), _P, C.POINTER(C.c_float))
+_sig("drt_renderer_render_batch", C.c_int, _P, C.POINTER(_CameraPOD), _P, C.c_uint32, C.POINTER(C.c_float))
+_sig("drt_renderer_reset", C.c_int, _P)
+for _n in ("width", "height", "sample_count", "local_rows"):
+    _sig("drt_renderer_%s" % _n, C.c_uint32, _P)
+_sig("drt_renderer_read_rgba32f", C.c_int, _P, _P, C.c_size_t)
+_sig("drt_renderer_read_accum", C.c_int, _P, _P, C.c_size_t)
+_sig("drt_renderer_device_rgba", _P, _P)
+_sig("drt_renderer_device_accum", _P, _P)
+_sig("drt_renderer_set_shard", C.c_int, _P, C.c_uint32, C.c_uint32, C.c_uint32)
+_sig("drt_renderer_bind_buffers", C.c_int, _P, _P, _P)
+_sig("drt_renderer_set_stream", C.c_int, _P, _P)
+_sig("drt_renderer_set_counting", C.c_int, _P, C.c_int32)
+_sig("drt_renderer_get_counters", C.c_int, _P, C.POINTER(Counters))
+_sig("drt_renderer_kernel_info", C.c_int, _P, C.c_char_p, C.c_size_t)
+_sig("drt_assemble_shards", C.c_int, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P)
+_sig("drt_shard_rows", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
+
+EXPORTED_SYMBOLS = [n for n in dir(_lib) if n.startswith("drt_")]
+
+
+def _check(rc):
+    if rc < 0:
+        raise DrtError(rc, (_lib.drt_last_error() or b"").decode("utf-8", "replace"))
+    return rc
+
+
+def _assign(struct, key, value):
+    cur = getattr(struct, key)
+    if hasattr(cur, "__len__"):
+        for i, v in enumerate(value):
+            cur[i] = v
+    else:
+        setattr(struct, key, value)
+
+
+def device_count():
+    return _lib.drt_device_count()
+
+
+def shard_rows(height, stripe_rows, rank, world):
+    return int(_lib.drt_shard_rows(height, stripe_rows, rank, world))
+
+
+class Scene:
+    """Core/Scene/Scene.cuh:41-57: loadGLTFmodel + the public buffers (as numpy copies)."""
+
+    def __init__(self):
+        self._h = _lib.drt_scene_create()
+        if not self._h:
+            raise DrtError(ERR_INVALID, "cannot create scene")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.drt_scene_destroy(h)
+
+    def loadGLTFmodel(self, filepath):
+        _check(_lib.drt_scene_load_gltf(self._h, os.fsencode(filepath)))
+        return True
+
+    def setGeometry(self, positions, normals, uvs, material_ids):
+        pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 9)
+        nrm = np.ascontiguousarray(normals, np.float32).reshape(-1, 9)
+        uv = np.ascontiguousarray(uvs, np.float32).reshape(-1, 6)
+        mat = np.ascontiguousarray(material_ids, np.int32)
+        _check(_lib.drt_scene_set_geometry(self._h, pos.ctypes.data, nrm.ctypes.data, uv.ctypes.data, mat.ctypes.data, len(mat)))
+
+    def addMaterial(self, albedo, albedo_tex=-1):
+        a = (C.c_float * 3)(*albedo)
+        return _check(_lib.drt_scene_add_material(self._h, a, albedo_tex))
+
+    def addTexture(self, texels):
+        t = np.ascontiguousarray(texels, np.uint8)
+        h, w, c = t.shape
+        return _check(_lib.drt_scene_add_texture(self._h, t.ctypes.data, w, h, c))
+
+    def _copy(self, getter, count, dtype):
+        out = np.zeros(count, dtype)
+        if count:
+            _check(getter(self._h, out.ctypes.data, count))
+        return out
+
+    @property
+    def m_PrimitivesBuffer(self):
+        return self._copy(_lib.drt_scene_get_triangles, _lib.drt_scene_triangle_count(self._h), TRIANGLE_DTYPE)
+
+    @property
+    def m_BVHNodes(self):
+        return self._copy(_lib.drt_scene_get_nodes, _lib.drt_scene_node_count(self._h), NODE_DTYPE)
+
+    @property
+    def m_Material(self):
+        return self._copy(_lib.drt_scene_get_materials, _lib.drt_scene_material_count(self._h), MATERIAL_DTYPE)
+
+    @property
+    def m_Meshes(self):
+        return self._copy(_lib.drt_scene_get_meshes, _lib.drt_scene_mesh_count(self._h), MESH_DTYPE)
+
+    @property
+    def m_Textures(self):
+        out = []
+        for i in range(_lib.drt_scene_texture_count(self._h)):
+            info = _TexInfo()
+            _check(_lib.drt_scene_get_texture_info(self._h, i, C.byref(info)))
+            tex = np.zeros((info.height, info.width, info.components), np.uint8)
+            _check(_lib.drt_scene_get_texture_texels(self._h, i, tex.ctypes.data, tex.size))
+            out.append(tex)
+        return out
+
+    @property
+    def bvh_depth(self):
+        return _lib.drt_scene_bvh_depth(self._h)
+
+
+class BVHBuilder:
+    """Core/BVH/BVHBuilder.cuh:12-23 (defaults of the class; the editor sets 20 / 8, EditorLayer.cpp:52-55)."""
+
+    def __init__(self):
+        self.m_BinCount = 8
+        self.m_TargetLeafPrimitivesCount = 6
+
+    def buildIterative(self, scene):
+        _check(_lib.drt_scene_build_bvh(scene._h, self.m_TargetLeafPrimitivesCount, self.m_BinCount))
+        return scene
+
+    build = buildIterative      # BVHBuilder.cu:100-173 produces the same tree through recursion
+
+
+class Renderer:
+    """Core/Renderer.hpp:14-47."""
+
+    def __init__(self, device=0):
+        self._h = _lib.drt_renderer_create(device)
+        if not self._h:
+            raise DrtError(ERR_DEVICE, (_lib.drt_last_error() or b"").decode())
+        self.m_RendererSettings = RendererSettings()
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.drt_renderer_destroy(h)
+
+    def ResizeBuffer(self, width, height):
+        _check(_lib.drt_renderer_resize(self._h, width, height))
+
+    def _push_settings(self):
+        _check(_lib.drt_renderer_set_settings(self._h, C.byref(self.m_RendererSettings)))
+
+    def Render(self, cam, scene):
+        """One frame index; returns the kernel time in ms (the reference's `float* delta`)."""
+        self._push_settings()
+        ms = C.c_float(0)
+        pod = cam._pod()
+        _check(_lib.drt_renderer_render(self._h, C.byref(pod), scene._h, C.byref(ms)))
+        return ms.value
+
+    def RenderBatch(self, cam, scene, n_frames):
+        self._push_settings()
+        ms = C.c_float(0)
+        pod = cam._pod()
+        _check(_lib.drt_renderer_render_batch(self._h, C.byref(pod), scene._h, n_frames, C.byref(ms)))
+        return ms.value
+
+    def resetAccumulationBuffer(self):
+        _check(_lib.drt_renderer_reset(self._h))
+
+    def getBufferWidth(self):
+        return _lib.drt_renderer_width(self._h)
+
+    def getBufferHeight(self):
+        return _lib.drt_renderer_height(self._h)
+
+    def getSampleCount(self):
+        return _lib.drt_renderer_sample_count(self._h)
+
+    def getLocalRows(self):
+        return _lib.drt_renderer_local_rows(self._h)
+
+    def GetRenderTargetImage(self):
+        """RGBA32F framebuffer as numpy [local_rows, width, 4]; row 0 = bottom (replaces the GL texture name)."""
+        out = np.zeros((self.getLocalRows(), self.getBufferWidth(), 4), np.float32)
+        _check(_lib.drt_renderer_read_rgba32f(self._h, out.ctypes.data, out.size))
+        return out
+
+    def GetAccumulationBuffer(self):
+        out = np.zeros((self.getLocalRows(), self.getBufferWidth(), 3), np.float32)
+        _check(_lib.drt_renderer_read_accum(self._h, out.ctypes.data, out.size))
+        return out
+
+    def setShard(self, stripe_rows, rank, world):
+        _check(_lib.drt_renderer_set_shard(self._h, stripe_rows, rank, world))
+
+    def bindBuffers(self, accum_ptr, rgba_ptr):
+        _check(_lib.drt_renderer_bind_buffers(self._h, accum_ptr, rgba_ptr))
+
+    def setStream(self, stream_ptr):
+        _check(_lib.drt_renderer_set_stream(self._h, stream_ptr))
+
+    def setCounting(self, enable):
+        _check(_lib.drt_renderer_set_counting(self._h, 1 if enable else 0))
+
+    def getCounters(self):
+        c = Counters()
+        _check(_lib.drt_renderer_get_counters(self._h, C.byref(c)))
+        return c
+
+    def kernelInfo(self):
+        buf = C.create_string_buffer(128)
+        _check(_lib.drt_renderer_kernel_info(self._h, buf, 128))
+        return buf.value.decode()
+
+
+def assemble_shards(gathered_ptr, image_ptr, width, height, stripe_rows, world, padded_rows, stream_ptr=None):
+    _check(_lib.drt_assemble_shards(gathered_ptr, image_ptr, width, height, stripe_rows, world, padded_rows, stream_ptr))

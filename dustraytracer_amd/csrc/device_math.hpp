@@ -1,0 +1,129 @@
+// device_math.hpp -- fp32 building blocks of the hot path, device side (gfx950).
+//
+// Every function states the reference lines it reproduces.  Bit-level rules (DESIGN.md "Numerics"):
+//   * compiled with -ffp-contract=off: each * and + is one IEEE rounding, in the reference's order
+//   * / and sqrtf are the correctly rounded forms (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt)
+//   * rsqrtf(x) is 1.0f / sqrtf(x) (helper_math.cuh:78-81), powf(x, 2) is x * x
+//   * fminf/fmaxf lower to v_min_f32/v_max_f32 in IEEE mode: a NaN operand is dropped, as on the CUDA device
+// Citations are relative to /root/reference/DustRayTracer/src/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+
+namespace drt {
+
+struct f3 { float x, y, z; };
+struct f2 { float x, y; };
+
+#define DRT_DEV __device__ __forceinline__
+
+DRT_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+DRT_DEV f3 ld3(const float *p) { return mk3(p[0], p[1], p[2]); }
+DRT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DRT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DRT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+DRT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+DRT_DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+DRT_DEV f3 operator/(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
+DRT_DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+DRT_DEV f3 add_scalar(f3 a, float s) { return mk3(a.x + s, a.y + s, a.z + s); }
+DRT_DEV f3 sub_scalar(f3 a, float s) { return mk3(a.x - s, a.y - s, a.z - s); }
+DRT_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                       // helper_math.cuh:1264
+DRT_DEV f3 cross(f3 a, f3 b) {                                                                    // helper_math.cuh:1436
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+DRT_DEV float length(f3 v) { return sqrtf(dot(v, v)); }                                           // helper_math.cuh:1307
+DRT_DEV f3 normalize(f3 v) { float inv_len = 1.0f / sqrtf(dot(v, v)); return v * inv_len; }       // helper_math.cuh:1325
+
+// ---- CudaMath/Random.cu ----
+DRT_DEV uint32_t pcg_hash(uint32_t input) {                                                       // :6-11
+    uint32_t state = input * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+DRT_DEV float random_float(uint32_t &seed) {                                                      // :13-17
+    seed = pcg_hash(seed);
+    return (float)seed / 4294967296.0f;       // (float)UINT32_MAX == 2^32
+}
+DRT_DEV f3 random_unit_vec3(uint32_t &seed) {                                                     // :42-48 (x, then y, then z)
+    float x = random_float(seed) * 2.f - 1.f;
+    float y = random_float(seed) * 2.f - 1.f;
+    float z = random_float(seed) * 2.f - 1.f;
+    return normalize(mk3(x, y, z));
+}
+DRT_DEV f3 random_unit_sphere_vec3(uint32_t &seed) {                                              // :50-58
+    for (;;) {
+        f3 p = random_unit_vec3(seed);
+        float len = length(p);
+        if ((len * len) < 1) return p;
+    }
+}
+DRT_DEV f2 random_in_unit_disk(uint32_t &seed) {                                                  // :60-66
+    for (;;) {
+        f2 p;
+        p.x = random_float(seed) * 2 - 1;
+        p.y = random_float(seed) * 2 - 1;
+        if (p.x * p.x + p.y * p.y < 1.0f) return p;
+    }
+}
+
+// ---- Core/Ray.cuh:5-24 ----
+struct Ray { f3 orig, dir, inv_dir; };
+DRT_DEV Ray make_ray(f3 o, f3 d) { Ray r; r.orig = o; r.dir = d; r.inv_dir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); return r; }
+
+// ---- Core/Bounds.cu:18-41 ----
+DRT_DEV float slab_intersect(f3 bmin, f3 bmax, const Ray &ray) {
+    f3 t0 = (bmin - ray.orig) * ray.inv_dir;
+    f3 t1 = (bmax - ray.orig) * ray.inv_dir;
+    f3 tmin = mk3(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z));
+    f3 tmax = mk3(fmaxf(t1.x, t0.x), fmaxf(t1.y, t0.y), fmaxf(t1.z, t0.z));
+    float tenter = fmaxf(fmaxf(tmin.x, tmin.y), tmin.z);
+    float texit = fminf(fminf(tmax.x, tmax.y), tmax.z);
+    if (tenter < 0.0f) tenter = 0.0f;
+    if (tenter > texit || texit < 0) return -1;
+    return tenter;
+}
+
+// ---- Kernel/Shaders/Intersection.cu:4-36 (edges precomputed: e1 = v1-v0, e2 = v2-v0) ----
+#define DRT_TRIANGLE_EPSILON 0.000001f     // Common/physical_units.hpp:12
+DRT_DEV bool tri_intersect(const Ray &ray, f3 v0, f3 e1, f3 e2, float &t_out, f3 &uvw) {
+    f3 pvec = cross(ray.dir, e2);
+    float det = dot(e1, pvec);
+    if (det > -DRT_TRIANGLE_EPSILON && det < DRT_TRIANGLE_EPSILON) return false;
+    float inv_det = 1.0f / det;
+    f3 tvec = ray.orig - v0;
+    float u = inv_det * dot(tvec, pvec);
+    if (u < 0.0f || u > 1.0f) return false;
+    f3 qvec = cross(tvec, e1);
+    float v = inv_det * dot(ray.dir, qvec);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t = inv_det * dot(e2, qvec);
+    if (t > DRT_TRIANGLE_EPSILON) {
+        t_out = t;
+        uvw = mk3(1.0f - u - v, u, v);
+        return true;
+    }
+    return false;
+}
+
+// ---- Shaders/RayGen.cuh:23-61 ----
+DRT_DEV f3 uncharted2_tonemap_partial(f3 x) {                                                     // :23-32
+    const float A = 0.15f, B = 0.50f, C = 0.10f, D = 0.20f, E = 0.02f, F = 0.30f;
+    f3 num = add_scalar(x * add_scalar(A * x, C * B), D * E);
+    f3 den = add_scalar(x * add_scalar(A * x, B), D * F);
+    return sub_scalar(num / den, E / F);
+}
+DRT_DEV f3 uncharted2_filmic(f3 v, float exposure) {                                              // :34-42
+    f3 curr = uncharted2_tonemap_partial(v * exposure);
+    f3 white_scale = mk3(1.0f, 1.0f, 1.0f) / uncharted2_tonemap_partial(mk3(11.2f, 11.2f, 11.2f));
+    return curr * white_scale;
+}
+DRT_DEV f3 gamma_correction(f3 c) { return mk3(sqrtf(c.x), sqrtf(c.y), sqrtf(c.z)); }             // :49-52
+DRT_DEV f3 sky_model(f3 dir, f3 sky_color) {                                                      // :54-61
+    float t = 0.5f * (1 + normalize(dir).y);      // 0.5 * float in double, rounded back: exact, == 0.5f * float
+    f3 c = ((1 - t) * mk3(1, 1, 1)) + (t * sky_color);
+    return mk3(c.x * c.x, c.y * c.y, c.z * c.z);
+}
+
+}  // namespace drt

@@ -1,0 +1,499 @@
+// drt_capi.cpp -- the C ABI of include/drt.h: scene handles, the renderer (device buffers, per-call
+// constants, launches, read-back) and error reporting.
+//
+// Replaces class Renderer (Core/Renderer.hpp:14-47, Core/Renderer.cu) and InvokeRenderKernel
+// (Core/Kernel/RenderKernel.cu:37-58).  No GL interop: the framebuffer is a device float4 array.
+#include "../../include/drt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <stdexcept>
+#include <string>
+
+#include "device_scene.hpp"
+#include "render_kernels.hpp"
+#include "scene_host.hpp"
+
+using namespace drt;
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+
+int from_exception() {
+    try {
+        throw;
+    } catch (const UnsupportedError &e) { return fail(DRT_ERR_UNSUPPORTED, e.what());
+    } catch (const IoError &e) { return fail(DRT_ERR_IO, e.what());
+    } catch (const BvhError &e) { return fail(DRT_ERR_BVH, e.what());
+    } catch (const std::invalid_argument &e) { return fail(DRT_ERR_INVALID, e.what());
+    } catch (const std::bad_alloc &) { return fail(DRT_ERR_INVALID, "out of host memory");
+    } catch (const std::exception &e) { return fail(DRT_ERR_PARSE, e.what());
+    } catch (...) { return fail(DRT_ERR_INVALID, "unknown error"); }
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(DRT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+template <class T>
+struct DeviceArray {
+    T *ptr = nullptr;
+    size_t count = 0;
+    hipError_t upload(const std::vector<T> &host) {
+        release();
+        count = host.size();
+        size_t bytes = std::max<size_t>(host.size(), 1) * sizeof(T);
+        hipError_t e = hipMalloc((void **)&ptr, bytes);
+        if (e != hipSuccess) { ptr = nullptr; return e; }
+        if (!host.empty()) e = hipMemcpy(ptr, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice);
+        return e;
+    }
+    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; count = 0; }
+};
+
+}  // namespace
+
+struct drt_scene {
+    HostScene host;
+};
+
+struct drt_renderer {
+    int device = 0;
+    drt_settings settings;
+    uint32_t width = 0, height = 0;
+    uint32_t frame_index = 1;                 // m_FrameIndex, Renderer.hpp:41
+    uint32_t stripe_rows = 1, rank = 0, world = 1, local_rows = 0;
+    float *accum = nullptr, *rgba = nullptr;  // internal buffers
+    float *ext_accum = nullptr, *ext_rgba = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool counting = false;
+    unsigned long long *counters = nullptr;
+    const char *kernel_name = "";
+    // device copy of the scene last rendered
+    const drt_scene *uploaded_scene = nullptr;
+    uint64_t uploaded_revision = 0;
+    DeviceArray<InnerNode> d_inner;
+    DeviceArray<LeafRange> d_leaves;
+    DeviceArray<TriHot> d_hot;
+    DeviceArray<TriCold> d_cold;
+    DeviceArray<MatDev> d_mats;
+    DeviceArray<TexDev> d_texs;
+    DeviceArray<uint8_t> d_texels;
+    SceneView view;
+    int bvh_depth = 0;
+
+    float *cur_accum() const { return ext_accum ? ext_accum : accum; }
+    float *cur_rgba() const { return ext_rgba ? ext_rgba : rgba; }
+    void free_scene() {
+        d_inner.release(); d_leaves.release(); d_hot.release(); d_cold.release();
+        d_mats.release(); d_texs.release(); d_texels.release();
+        uploaded_scene = nullptr;
+    }
+};
+
+extern "C" {
+
+int drt_abi_version(void) { return DRT_ABI_VERSION; }
+const char *drt_last_error(void) { return g_error.c_str(); }
+
+int drt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void drt_default_settings(drt_settings *s) {
+    if (!s) return;
+    std::memset(s, 0, sizeof *s);
+    s->gamma_correction = 1; s->tone_mapping = 1; s->enable_sunlight = 0;
+    s->max_samples = 500; s->ray_bounce_limit = 2; s->render_mode = 0; s->debug_mode = 0;
+    s->sunlight_dir[0] = -0.803f; s->sunlight_dir[1] = 0.681f;
+    s->sunlight_color[0] = 1.000f; s->sunlight_color[1] = 0.944f; s->sunlight_color[2] = 0.917f;
+    s->sunlight_intensity = 30;
+    s->sky_color[0] = 0.25f; s->sky_color[1] = 0.498f; s->sky_color[2] = 0.80f;
+    s->sky_intensity = 20;
+}
+
+void drt_default_camera(drt_camera *c) {
+    if (!c) return;
+    const float PI = 3.14159265359f;             // deg2rad, Camera.cu:125-129
+    c->exposure = 1;
+    c->vfov_rad = 60 * (PI / 180.f);
+    c->defocus_angle = 0;
+    c->focus_dist = 10;
+    c->position[0] = 0; c->position[1] = 2; c->position[2] = 5;
+    c->forward[0] = 0; c->forward[1] = 0; c->forward[2] = -1;
+}
+
+// ------------------------------------------------------------------ scene
+drt_scene *drt_scene_create(void) {
+    try { return new drt_scene(); } catch (...) { from_exception(); return nullptr; }
+}
+void drt_scene_destroy(drt_scene *s) { delete s; }
+
+int drt_scene_load_gltf(drt_scene *s, const char *path) {
+    if (!s || !path) return fail(DRT_ERR_INVALID, "null argument");
+    try { s->host.load_gltf(path); return DRT_OK; } catch (...) { return from_exception(); }
+}
+
+int drt_scene_set_geometry(drt_scene *s, const float *positions, const float *normals, const float *uvs,
+                           const int32_t *material_ids, int32_t n_tris) {
+    if (!s || n_tris < 0 || (n_tris > 0 && (!positions || !normals || !uvs || !material_ids)))
+        return fail(DRT_ERR_INVALID, "null argument");
+    try {
+        s->host.triangles.clear(); s->host.meshes.clear();
+        s->host.set_geometry(positions, normals, uvs, material_ids, n_tris);
+        return DRT_OK;
+    } catch (...) { return from_exception(); }
+}
+
+int drt_scene_add_material(drt_scene *s, const float albedo[3], int32_t albedo_tex) {
+    if (!s || !albedo) return fail(DRT_ERR_INVALID, "null argument");
+    try {
+        drt_material m;
+        std::memset(&m, 0, sizeof m);
+        std::memcpy(m.albedo, albedo, 12);
+        m.albedo_tex = albedo_tex;
+        m.refractive_index = 1.45f;
+        s->host.materials.push_back(m);
+        ++s->host.revision;
+        return (int)s->host.materials.size() - 1;
+    } catch (...) { return from_exception(); }
+}
+
+int drt_scene_add_texture(drt_scene *s, const uint8_t *texels, int32_t width, int32_t height, int32_t components) {
+    if (!s || !texels || width <= 0 || height <= 0 || components < 1 || components > 4)
+        return fail(DRT_ERR_INVALID, "bad texture");
+    try {
+        HostTexture t;
+        t.width = width; t.height = height; t.components = components;
+        t.texels.assign(texels, texels + (size_t)width * height * components);
+        s->host.textures.push_back(std::move(t));
+        ++s->host.revision;
+        return (int)s->host.textures.size() - 1;
+    } catch (...) { return from_exception(); }
+}
+
+int drt_scene_build_bvh(drt_scene *s, int32_t target_leaf_prims, int32_t bin_count) {
+    if (!s) return fail(DRT_ERR_INVALID, "null scene");
+    try { s->host.build_bvh(target_leaf_prims, bin_count); return DRT_OK; } catch (...) { return from_exception(); }
+}
+
+int32_t drt_scene_triangle_count(const drt_scene *s) { return s ? (int32_t)s->host.triangles.size() : 0; }
+int32_t drt_scene_node_count(const drt_scene *s) { return s ? (int32_t)s->host.nodes.size() : 0; }
+int32_t drt_scene_material_count(const drt_scene *s) { return s ? (int32_t)s->host.materials.size() : 0; }
+int32_t drt_scene_texture_count(const drt_scene *s) { return s ? (int32_t)s->host.textures.size() : 0; }
+int32_t drt_scene_mesh_count(const drt_scene *s) { return s ? (int32_t)s->host.meshes.size() : 0; }
+int32_t drt_scene_bvh_depth(const drt_scene *s) { return s ? s->host.bvh_depth() : 0; }
+
+#define DRT_COPY_OUT(vec)                                                                          \
+    if (!s || (!out && cap > 0) || cap < 0) return fail(DRT_ERR_INVALID, "bad argument");          \
+    {                                                                                              \
+        size_t n = std::min<size_t>((size_t)cap, s->host.vec.size());                              \
+        if (n) std::memcpy(out, s->host.vec.data(), n * sizeof(s->host.vec[0]));                   \
+        return (int)n;                                                                             \
+    }
+
+int drt_scene_get_triangles(const drt_scene *s, drt_triangle *out, int32_t cap) { DRT_COPY_OUT(triangles) }
+int drt_scene_get_nodes(const drt_scene *s, drt_bvh_node *out, int32_t cap) { DRT_COPY_OUT(nodes) }
+int drt_scene_get_materials(const drt_scene *s, drt_material *out, int32_t cap) { DRT_COPY_OUT(materials) }
+int drt_scene_get_meshes(const drt_scene *s, drt_mesh *out, int32_t cap) { DRT_COPY_OUT(meshes) }
+
+int drt_scene_get_texture_info(const drt_scene *s, int32_t index, drt_texture_info *out) {
+    if (!s || !out || index < 0 || (size_t)index >= s->host.textures.size()) return fail(DRT_ERR_INVALID, "bad texture index");
+    const HostTexture &t = s->host.textures[(size_t)index];
+    out->width = t.width; out->height = t.height; out->components = t.components;
+    return DRT_OK;
+}
+
+int drt_scene_get_texture_texels(const drt_scene *s, int32_t index, uint8_t *out, size_t cap) {
+    if (!s || !out || index < 0 || (size_t)index >= s->host.textures.size()) return fail(DRT_ERR_INVALID, "bad texture index");
+    const HostTexture &t = s->host.textures[(size_t)index];
+    if (cap < t.texels.size()) return fail(DRT_ERR_INVALID, "destination too small");
+    std::memcpy(out, t.texels.data(), t.texels.size());
+    return DRT_OK;
+}
+
+// ------------------------------------------------------------------ renderer
+uint32_t drt_shard_rows(uint32_t height, uint32_t stripe_rows, uint32_t rank, uint32_t world) {
+    if (stripe_rows == 0 || world == 0 || rank >= world) return 0;
+    uint32_t stripes = (height + stripe_rows - 1) / stripe_rows, rows = 0;
+    for (uint32_t s = rank; s < stripes; s += world)
+        rows += std::min(stripe_rows, height - s * stripe_rows);
+    return rows;
+}
+
+static int realloc_buffers(drt_renderer *r) {
+    HIP_TRY(hipSetDevice(r->device));
+    if (r->accum) { (void)hipFree(r->accum); r->accum = nullptr; }
+    if (r->rgba) { (void)hipFree(r->rgba); r->rgba = nullptr; }
+    r->local_rows = drt_shard_rows(r->height, r->stripe_rows, r->rank, r->world);
+    size_t px = std::max<size_t>((size_t)r->width * r->local_rows, 1);
+    HIP_TRY(hipMalloc((void **)&r->accum, px * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&r->rgba, px * 4 * sizeof(float)));
+    HIP_TRY(hipMemset(r->rgba, 0, px * 4 * sizeof(float)));
+    return DRT_OK;
+}
+
+drt_renderer *drt_renderer_create(int32_t device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        fail(DRT_ERR_DEVICE, "no usable HIP device: this library has no CPU fallback");
+        return nullptr;
+    }
+    if (device < 0 || device >= n) { fail(DRT_ERR_INVALID, "device index out of range"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { fail(DRT_ERR_DEVICE, "hipSetDevice failed"); return nullptr; }
+    drt_renderer *r = nullptr;
+    try { r = new drt_renderer(); } catch (...) { from_exception(); return nullptr; }
+    r->device = device;
+    drt_default_settings(&r->settings);
+    if (hipEventCreate(&r->ev_start) != hipSuccess || hipEventCreate(&r->ev_stop) != hipSuccess ||
+        hipMalloc((void **)&r->counters, sizeof(drt_counters)) != hipSuccess) {
+        fail(DRT_ERR_DEVICE, "cannot create HIP events / counter buffer");
+        drt_renderer_destroy(r);
+        return nullptr;
+    }
+    return r;
+}
+
+void drt_renderer_destroy(drt_renderer *r) {
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    r->free_scene();
+    if (r->accum) (void)hipFree(r->accum);
+    if (r->rgba) (void)hipFree(r->rgba);
+    if (r->counters) (void)hipFree(r->counters);
+    if (r->ev_start) (void)hipEventDestroy(r->ev_start);
+    if (r->ev_stop) (void)hipEventDestroy(r->ev_stop);
+    delete r;
+}
+
+int drt_renderer_reset(drt_renderer *r) {                      // Renderer.cu:132-136
+    if (!r) return fail(DRT_ERR_INVALID, "null renderer");
+    HIP_TRY(hipSetDevice(r->device));
+    if (r->cur_accum() && r->width && r->local_rows)
+        HIP_TRY(hipMemsetAsync(r->cur_accum(), 0, (size_t)r->width * r->local_rows * 3 * sizeof(float), r->stream));
+    r->frame_index = 1;
+    return DRT_OK;
+}
+
+int drt_renderer_resize(drt_renderer *r, uint32_t width, uint32_t height) {   // Renderer.cu:29-78
+    if (!r) return fail(DRT_ERR_INVALID, "null renderer");
+    if (width == r->width && height == r->height) return DRT_OK;
+    if ((uint64_t)width * height > (1ull << 31)) return fail(DRT_ERR_INVALID, "framebuffer too large (pixel index is 32-bit, RayGen.cuh:74)");
+    if (r->ext_accum || r->ext_rgba) return fail(DRT_ERR_INVALID, "unbind external buffers before resizing");
+    r->width = width; r->height = height;
+    int rc = realloc_buffers(r);
+    if (rc != DRT_OK) return rc;
+    return drt_renderer_reset(r);
+}
+
+int drt_renderer_set_shard(drt_renderer *r, uint32_t stripe_rows, uint32_t rank, uint32_t world) {
+    if (!r || stripe_rows == 0 || world == 0 || rank >= world) return fail(DRT_ERR_INVALID, "bad shard description");
+    if (r->ext_accum || r->ext_rgba) return fail(DRT_ERR_INVALID, "unbind external buffers before re-sharding");
+    r->stripe_rows = stripe_rows; r->rank = rank; r->world = world;
+    if (r->width && r->height) {
+        int rc = realloc_buffers(r);
+        if (rc != DRT_OK) return rc;
+        return drt_renderer_reset(r);
+    }
+    return DRT_OK;
+}
+
+int drt_renderer_bind_buffers(drt_renderer *r, void *device_accum, void *device_rgba) {
+    if (!r) return fail(DRT_ERR_INVALID, "null renderer");
+    if ((device_accum == nullptr) != (device_rgba == nullptr)) return fail(DRT_ERR_INVALID, "bind both buffers or neither");
+    r->ext_accum = (float *)device_accum;
+    r->ext_rgba = (float *)device_rgba;
+    return DRT_OK;
+}
+
+int drt_renderer_set_stream(drt_renderer *r, void *hip_stream) {
+    if (!r) return fail(DRT_ERR_INVALID, "null renderer");
+    r->stream = (hipStream_t)hip_stream;
+    return DRT_OK;
+}
+
+int drt_renderer_set_settings(drt_renderer *r, const drt_settings *s) {
+    if (!r || !s) return fail(DRT_ERR_INVALID, "null argument");
+    r->settings = *s;
+    return DRT_OK;
+}
+int drt_renderer_get_settings(const drt_renderer *r, drt_settings *out) {
+    if (!r || !out) return fail(DRT_ERR_INVALID, "null argument");
+    *out = r->settings;
+    return DRT_OK;
+}
+
+uint32_t drt_renderer_width(const drt_renderer *r) { return r ? r->width : 0; }
+uint32_t drt_renderer_height(const drt_renderer *r) { return r ? r->height : 0; }
+uint32_t drt_renderer_sample_count(const drt_renderer *r) { return r ? r->frame_index : 0; }
+uint32_t drt_renderer_local_rows(const drt_renderer *r) { return r ? r->local_rows : 0; }
+void *drt_renderer_device_rgba(drt_renderer *r) { return r ? r->cur_rgba() : nullptr; }
+void *drt_renderer_device_accum(drt_renderer *r) { return r ? r->cur_accum() : nullptr; }
+
+int drt_renderer_set_counting(drt_renderer *r, int32_t enable) {
+    if (!r) return fail(DRT_ERR_INVALID, "null renderer");
+    r->counting = enable != 0;
+    return DRT_OK;
+}
+
+int drt_renderer_get_counters(drt_renderer *r, drt_counters *out) {
+    if (!r || !out) return fail(DRT_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(hipMemcpy(out, r->counters, sizeof *out, hipMemcpyDeviceToHost));
+    return DRT_OK;
+}
+
+int drt_renderer_kernel_info(const drt_renderer *r, char *buf, size_t cap) {
+    if (!r || !buf || cap == 0) return fail(DRT_ERR_INVALID, "bad argument");
+    std::snprintf(buf, cap, "%s", r->kernel_name);
+    return DRT_OK;
+}
+
+static int upload_scene(drt_renderer *r, const drt_scene *scene) {
+    if (r->uploaded_scene == scene && r->uploaded_revision == scene->host.revision) return DRT_OK;
+    PackedScene ps;
+    try { ps = scene->host.pack(); } catch (...) { return from_exception(); }
+    r->free_scene();
+    HIP_TRY(r->d_inner.upload(ps.inner));
+    HIP_TRY(r->d_leaves.upload(ps.leaves));
+    HIP_TRY(r->d_hot.upload(ps.tri_hot));
+    HIP_TRY(r->d_cold.upload(ps.tri_cold));
+    HIP_TRY(r->d_mats.upload(ps.mats));
+    HIP_TRY(r->d_texs.upload(ps.texs));
+    HIP_TRY(r->d_texels.upload(ps.texels));
+    SceneView &v = r->view;
+    v.inner = r->d_inner.ptr; v.leaves = r->d_leaves.ptr; v.tri_hot = r->d_hot.ptr; v.tri_cold = r->d_cold.ptr;
+    v.mats = r->d_mats.ptr; v.texs = r->d_texs.ptr; v.texels = r->d_texels.ptr;
+    v.n_inner = (uint32_t)ps.inner.size(); v.n_leaves = (uint32_t)ps.leaves.size();
+    v.n_tris = (uint32_t)ps.tri_hot.size(); v.n_mats = (uint32_t)ps.mats.size(); v.n_texs = (uint32_t)ps.texs.size();
+    v.root_ref = ps.root_ref;
+    std::memcpy(v.root_min, ps.root_min, 12);
+    std::memcpy(v.root_max, ps.root_max, 12);
+    r->bvh_depth = ps.depth;
+    r->uploaded_scene = scene;
+    r->uploaded_revision = scene->host.revision;
+    return DRT_OK;
+}
+
+// Per-frame constants of Camera::GetRay (Camera.cu:84-103) and RayGen (RayGen.cuh:68-72), computed on the
+// host with the same fp32 operations in the same order (host libm for tan/sin/cos).
+static void fill_frame_params(const drt_renderer *r, const drt_camera *cam, FrameParams &fp) {
+    const drt_settings &s = r->settings;
+    const float width = (float)r->width, height = (float)r->height;       // Camera.cu:82 takes floats
+    float theta = cam->vfov_rad / 2;
+    float fov_factor = tanf(theta / 2.0f);
+    float aspect_ratio = width / height;
+    float plane_h = 2.0f * fov_factor * cam->focus_dist;
+    float plane_w = plane_h * aspect_ratio;
+    V3 forward_dir = normalize(V3{ cam->forward[0], cam->forward[1], cam->forward[2] });
+    V3 right_dir = normalize(cross(forward_dir, V3{ 0, 1, 0 }));
+    V3 up_dir = cross(right_dir, forward_dir);
+    V3 horizontal = plane_w * right_dir, vertical = plane_h * up_dir;
+    const float PI = 3.14159265359f;
+    float defocus_radius = cam->focus_dist * tanf((cam->defocus_angle * (PI / 180.f)) / 2.0f);
+    V3 disk_u = defocus_radius * right_dir, disk_v = defocus_radius * up_dir;
+    V3 fwd_focus = forward_dir * cam->focus_dist;
+    auto put = [](float *dst, V3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; };
+    std::memcpy(fp.cam_pos, cam->position, 12);
+    put(fp.fwd_focus, fwd_focus); put(fp.horizontal, horizontal); put(fp.vertical, vertical);
+    put(fp.disk_u, disk_u); put(fp.disk_v, disk_v);
+    fp.defocus = !(cam->defocus_angle <= 0);
+    fp.exposure = cam->exposure;
+
+    float sx = sinf(s.sunlight_dir[0]), sy = sinf(s.sunlight_dir[1]), cx = cosf(s.sunlight_dir[0]);
+    put(fp.sunpos, V3{ sx * (1 - sy), sy, cx * (1 - sy) } * 100.0f);
+    put(fp.suncol, V3{ s.sunlight_color[0], s.sunlight_color[1], s.sunlight_color[2] } * s.sunlight_intensity);
+    std::memcpy(fp.sky_color, s.sky_color, 12);
+    fp.sky_intensity = s.sky_intensity;
+    fp.gamma_correction = s.gamma_correction != 0; fp.tone_mapping = s.tone_mapping != 0;
+    fp.enable_sunlight = s.enable_sunlight != 0;
+    fp.bounce_limit = s.ray_bounce_limit;
+    fp.render_mode = s.render_mode; fp.debug_mode = s.debug_mode;
+    fp.width = r->width; fp.height = r->height;
+    fp.stripe_rows = r->stripe_rows; fp.rank = r->rank; fp.world = r->world; fp.local_rows = r->local_rows;
+    fp.accum = r->cur_accum(); fp.rgba = r->cur_rgba();
+    fp.counters = r->counting ? r->counters : nullptr;
+}
+
+int drt_renderer_render_batch(drt_renderer *r, const drt_camera *cam, const drt_scene *scene, uint32_t n_frames,
+                              float *delta_ms) {
+    if (!r || !cam || !scene) return fail(DRT_ERR_INVALID, "null argument");
+    if (delta_ms) *delta_ms = 0.f;
+    if (r->width == 0 || r->height == 0) return fail(DRT_ERR_INVALID, "ResizeBuffer has not been called");
+    // Renderer.cu:82: nothing happens once m_FrameIndex == max_samples, so at most max_samples-1 frames accumulate.
+    if ((int64_t)r->frame_index == (int64_t)r->settings.max_samples) return DRT_OK;
+    if (r->settings.max_samples > 0 && r->frame_index < (uint32_t)r->settings.max_samples)
+        n_frames = std::min<uint32_t>(n_frames, (uint32_t)r->settings.max_samples - r->frame_index);
+    if (n_frames == 0) return DRT_OK;
+    HIP_TRY(hipSetDevice(r->device));
+    int rc = upload_scene(r, scene);
+    if (rc != DRT_OK) return rc;
+    if (r->bvh_depth > 64) return fail(DRT_ERR_UNSUPPORTED, "BVH deeper than 64 levels (the reference's traversal stack, BVHTraversal.cuh:17)");
+
+    FrameParams fp;
+    std::memset(&fp, 0, sizeof fp);
+    fill_frame_params(r, cam, fp);
+    fp.frame_first = r->frame_index;
+    fp.n_frames = n_frames;
+    if (r->counting) HIP_TRY(hipMemsetAsync(r->counters, 0, sizeof(drt_counters), r->stream));
+
+    HIP_TRY(hipEventRecord(r->ev_start, r->stream));                   // Renderer.cu:97
+    HIP_TRY(launch_render(r->view, fp, r->bvh_depth, r->counting, r->stream, &r->kernel_name));
+    HIP_TRY(hipEventRecord(r->ev_stop, r->stream));                    // Renderer.cu:105
+    HIP_TRY(hipEventSynchronize(r->ev_stop));                          // blocking, Renderer.cu:106
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, r->ev_start, r->ev_stop));
+    if (delta_ms) *delta_ms = ms;
+    r->frame_index += n_frames;                                        // Renderer.cu:116
+    return DRT_OK;
+}
+
+int drt_renderer_render(drt_renderer *r, const drt_camera *cam, const drt_scene *scene, float *delta_ms) {
+    return drt_renderer_render_batch(r, cam, scene, 1, delta_ms);
+}
+
+static int read_back(drt_renderer *r, const float *src, int comps, float *dst, size_t dst_floats) {
+    if (!r || !dst) return fail(DRT_ERR_INVALID, "null argument");
+    size_t need = (size_t)r->width * r->local_rows * (size_t)comps;
+    if (dst_floats < need) return fail(DRT_ERR_INVALID, "destination too small");
+    if (need == 0) return DRT_OK;
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(hipMemcpy(dst, src, need * sizeof(float), hipMemcpyDeviceToHost));
+    return DRT_OK;
+}
+
+int drt_renderer_read_rgba32f(drt_renderer *r, float *dst, size_t dst_floats) {
+    return read_back(r, r ? r->cur_rgba() : nullptr, 4, dst, dst_floats);
+}
+int drt_renderer_read_accum(drt_renderer *r, float *dst, size_t dst_floats) {
+    return read_back(r, r ? r->cur_accum() : nullptr, 3, dst, dst_floats);
+}
+
+int drt_assemble_shards(const void *gathered, void *image, uint32_t width, uint32_t height, uint32_t stripe_rows,
+                        uint32_t world, uint32_t padded_rows, void *hip_stream) {
+    if (!gathered || !image || stripe_rows == 0 || world == 0) return fail(DRT_ERR_INVALID, "bad argument");
+    if (padded_rows < drt_shard_rows(height, stripe_rows, 0, world)) return fail(DRT_ERR_INVALID, "padded_rows smaller than rank 0's shard");
+    HIP_TRY(launch_assemble(gathered, image, width, height, stripe_rows, world, padded_rows, (hipStream_t)hip_stream));
+    return DRT_OK;
+}
+
+}  // extern "C"

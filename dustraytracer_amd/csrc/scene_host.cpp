@@ -1,0 +1,480 @@
+// scene_host.cpp -- glTF flattening + binned-SAH BVH build + device packing (host prep for the hot path).
+//
+// Written from scratch; reproduces the *decisions* of the reference so that the triangle order, the node
+// array and therefore the rendered image are identical:
+//   Scene::loadGLTFmodel / parseMesh / loadMaterials / loadTextures   Core/Scene/Scene.cu:59-317
+//   BVHBuilder::buildIterative / makePartition / binToShallowNodes / binToNodes   Core/BVH/BVHBuilder.cu:11-346
+// Compile with -ffp-contract=off: every product and sum below rounds on its own, like the reference's
+// host code built without FMA.
+#include "scene_host.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+#include "json_min.hpp"
+#include "png_decode.hpp"
+
+namespace drt {
+
+V3 normalize(V3 v) {
+    float inv_len = 1.0f / sqrtf(dot(v, v));
+    return v * inv_len;
+}
+
+static inline V3 ld(const float *p) { return V3{ p[0], p[1], p[2] }; }
+static inline void st(float *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+
+void HostScene::clear() {
+    triangles.clear(); materials.clear(); textures.clear(); meshes.clear(); nodes.clear();
+    ++revision;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Triangle assembly (Scene.cu:272-302, Triangle.cuh:9-12)
+// ---------------------------------------------------------------------------------------------
+static drt_triangle make_triangle(const float *pos, const float *nrm, const float *uv, int32_t material) {
+    drt_triangle t;
+    std::memset(&t, 0, sizeof t);
+    V3 P[3], N[3];
+    for (int k = 0; k < 3; k++) {
+        P[k] = ld(pos + 3 * k);
+        N[k] = ld(nrm + 3 * k);
+        st(t.vertex[k].position, P[k]);
+        st(t.vertex[k].normal, N[k]);
+        t.vertex[k].uv[0] = uv[2 * k];
+        t.vertex[k].uv[1] = uv[2 * k + 1];
+    }
+    V3 face = cross(P[1] - P[0], P[2] - P[0]);
+    V3 avg = (N[0] + N[1] + N[2]) / 3;
+    float ndot = dot(face, avg);
+    V3 oriented = (ndot < 0.0f) ? v3(-face.x, -face.y, -face.z) : face;
+    st(t.face_normal, normalize(oriented));
+    st(t.centroid, (P[0] + P[1] + P[2]) / 3);
+    t.material = material;
+    return t;
+}
+
+void HostScene::set_geometry(const float *pos, const float *nrm, const float *uv, const int32_t *mat, int32_t n_tris) {
+    drt_mesh mesh;
+    mesh.primitives_offset = (int32_t)triangles.size();
+    for (int32_t i = 0; i < n_tris; i++)
+        triangles.push_back(make_triangle(pos + 9 * (size_t)i, nrm + 9 * (size_t)i, uv + 6 * (size_t)i, mat[i]));
+    mesh.tris_count = n_tris;
+    meshes.push_back(mesh);
+    nodes.clear();
+    ++revision;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GLB container + the JSON fields the reference consumes
+// ---------------------------------------------------------------------------------------------
+static std::vector<uint8_t> read_file(const char *path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw IoError(std::string("cannot open ") + path);
+    f.seekg(0, std::ios::end);
+    std::streamoff n = f.tellg();
+    f.seekg(0, std::ios::beg);
+    std::vector<uint8_t> data((size_t)std::max<std::streamoff>(n, 0));
+    if (n > 0 && !f.read((char *)data.data(), n)) throw IoError(std::string("cannot read ") + path);
+    return data;
+}
+
+static uint32_t le32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+struct BufferView { int64_t buffer = 0, offset = 0, length = 0; };
+
+void HostScene::load_gltf(const char *path) {
+    std::string spath(path ? path : "");
+    size_t dot_at = spath.find_last_of('.');
+    std::string ext = dot_at == std::string::npos ? "" : spath.substr(dot_at + 1);
+    if (ext != "glb")   // Scene.cu:38-41: the ASCII branch needs external .bin / image files relative to "../models/"
+        throw UnsupportedError("only binary glTF (.glb) is supported; no BASELINE scene uses the ASCII branch");
+
+    std::vector<uint8_t> blob = read_file(path);
+    if (blob.size() < 20 || std::memcmp(blob.data(), "glTF", 4) != 0) throw std::runtime_error("not a GLB file");
+    if (le32(blob.data() + 4) != 2) throw UnsupportedError("glTF container version != 2");
+    size_t total = std::min<size_t>(le32(blob.data() + 8), blob.size());
+    const uint8_t *json_p = nullptr, *bin_p = nullptr;
+    size_t json_n = 0, bin_n = 0;
+    for (size_t off = 12; off + 8 <= total;) {
+        uint32_t clen = le32(blob.data() + off), ctype = le32(blob.data() + off + 4);
+        if ((size_t)clen > total - off - 8) throw std::runtime_error("GLB chunk runs past end of file");
+        if (ctype == 0x4E4F534Au && !json_p) { json_p = blob.data() + off + 8; json_n = clen; }
+        else if (ctype == 0x004E4942u && !bin_p) { bin_p = blob.data() + off + 8; bin_n = clen; }
+        off += 8 + (size_t)clen + ((4 - clen % 4) % 4);
+    }
+    if (!json_p) throw std::runtime_error("GLB has no JSON chunk");
+    JsonValue root = JsonParser((const char *)json_p, json_n).parse();
+
+    // buffers: the GLB-embedded buffer is the BIN chunk, truncated to byteLength
+    std::vector<std::pair<const uint8_t *, size_t>> buffers;
+    const JsonValue &jbuffers = root.at("buffers");
+    for (size_t i = 0; i < jbuffers.size(); i++) {
+        const JsonValue &b = jbuffers.at(i);
+        if (b.has("uri")) throw UnsupportedError("external / data-URI buffers are outside the supported subset");
+        size_t len = (size_t)b.at("byteLength").as_int(0);
+        if (len > bin_n) throw std::runtime_error("buffer.byteLength exceeds the BIN chunk");
+        buffers.emplace_back(bin_p, len);
+    }
+    std::vector<BufferView> views;
+    const JsonValue &jviews = root.at("bufferViews");
+    for (size_t i = 0; i < jviews.size(); i++) {
+        BufferView v;
+        v.buffer = jviews.at(i).at("buffer").as_int(0);
+        v.offset = jviews.at(i).at("byteOffset").as_int(0);
+        v.length = jviews.at(i).at("byteLength").as_int(0);
+        if (v.buffer < 0 || (size_t)v.buffer >= buffers.size() || v.offset < 0 || v.length < 0 ||
+            (size_t)(v.offset + v.length) > buffers[(size_t)v.buffer].second)
+            throw std::runtime_error("bufferView out of range");
+        views.push_back(v);
+    }
+    const JsonValue &jaccessors = root.at("accessors");
+    auto accessor_view = [&](int64_t accessor) -> const BufferView & {
+        if (accessor < 0 || (size_t)accessor >= jaccessors.size()) throw std::runtime_error("accessor index out of range");
+        int64_t bv = jaccessors.at((size_t)accessor).at("bufferView").as_int(-1);
+        if (bv < 0 || (size_t)bv >= views.size()) throw std::runtime_error("accessor without bufferView");
+        return views[(size_t)bv];
+    };
+
+    HostScene fresh;
+
+    // loadTextures (Scene.cu:88-117): one texture per IMAGE, decoded from its bufferView
+    const JsonValue &jimages = root.at("images");
+    for (size_t i = 0; i < jimages.size(); i++) {
+        int64_t bv = jimages.at(i).at("bufferView").as_int(-1);
+        if (bv < 0 || (size_t)bv >= views.size()) throw UnsupportedError("image without bufferView (URI images) not supported");
+        const BufferView &v = views[(size_t)bv];
+        const uint8_t *p = buffers[(size_t)v.buffer].first + v.offset;
+        if (!looks_like_png(p, (size_t)v.length)) throw UnsupportedError("embedded image is not a PNG");
+        DecodedImage img = decode_png(p, (size_t)v.length);
+        HostTexture t;
+        t.width = img.width; t.height = img.height; t.components = img.components;
+        t.texels = std::move(img.texels);
+        fresh.textures.push_back(std::move(t));
+    }
+
+    // loadMaterials (Scene.cu:59-86); tinygltf defaults: baseColorFactor [1,1,1,1], texture index -1, emissive 0
+    const JsonValue &jmats = root.at("materials");
+    for (size_t i = 0; i < jmats.size(); i++) {
+        const JsonValue &pbr = jmats.at(i).at("pbrMetallicRoughness");
+        drt_material m;
+        std::memset(&m, 0, sizeof m);
+        const JsonValue &col = pbr.at("baseColorFactor");
+        for (int k = 0; k < 3; k++) m.albedo[k] = (float)(col.size() >= 3 ? col.at((size_t)k).as_double(1.0) : 1.0);
+        const JsonValue &em = jmats.at(i).at("emissiveFactor");
+        for (int k = 0; k < 3; k++) m.emissive[k] = (float)(em.size() >= 3 ? em.at((size_t)k).as_double(0.0) : 0.0);
+        m.albedo_tex = (int32_t)pbr.at("baseColorTexture").at("index").as_int(-1);
+        m.roughness = (float)pbr.at("roughnessFactor").as_double(1.0);
+        m.metallic = pbr.at("metallicFactor").as_double(1.0) > 0;
+        m.transmission = 0;
+        m.refractive_index = 1.45f;
+        fresh.materials.push_back(m);
+    }
+
+    // loadGLTFmodel (Scene.cu:192-314): every NODE contributes its mesh; transforms are ignored
+    const JsonValue &jnodes = root.at("nodes");
+    const JsonValue &jmeshes = root.at("meshes");
+    for (size_t n = 0; n < jnodes.size(); n++) {
+        int64_t mesh_index = jnodes.at(n).at("mesh").as_int(-1);
+        if (mesh_index < 0 || (size_t)mesh_index >= jmeshes.size())
+            throw UnsupportedError("node without a mesh: the reference indexes meshes[-1] here (Scene.cu:199-200)");
+        std::vector<float> pos, nrm, uv;
+        std::vector<int32_t> mat;
+        const JsonValue &prims = jmeshes.at((size_t)mesh_index).at("primitives");
+        for (size_t p = 0; p < prims.size(); p++) {   // parseMesh (Scene.cu:120-178)
+            const JsonValue &prim = prims.at(p);
+            const JsonValue &attrs = prim.at("attributes");
+            // a missing attribute silently maps to accessor 0 (std::map::operator[], Scene.cu:129-131)
+            const BufferView &vp = accessor_view(attrs.at("POSITION").as_int(0));
+            const BufferView &vn = accessor_view(attrs.at("NORMAL").as_int(0));
+            const BufferView &vt = accessor_view(attrs.at("TEXCOORD_0").as_int(0));
+            int64_t idx_accessor = prim.at("indices").as_int(-1);
+            if (idx_accessor < 0) throw UnsupportedError("non-indexed primitive (the reference indexes accessors[-1])");
+            const BufferView &vi = accessor_view(idx_accessor);
+            const uint8_t *base = buffers[(size_t)vi.buffer].first;     // everything is read from the INDICES' buffer
+            size_t base_len = buffers[(size_t)vi.buffer].second;
+            int64_t i0 = vi.offset / 2, i1 = (vi.length + vi.offset) / 2;    // u16 units from byte 0 (Scene.cu:161,166)
+            for (int64_t i = i0; i < i1; i++) {
+                uint16_t index;
+                std::memcpy(&index, base + 2 * (size_t)i, 2);
+                size_t op = (size_t)vp.offset + 12u * index, on = (size_t)vn.offset + 12u * index, ot = (size_t)vt.offset + 8u * index;
+                if (op + 12 > base_len || on + 12 > base_len || ot + 8 > base_len)
+                    throw std::runtime_error("vertex index reads past the buffer");
+                float f[3];
+                std::memcpy(f, base + op, 12); pos.insert(pos.end(), f, f + 3);
+                std::memcpy(f, base + on, 12); nrm.insert(nrm.end(), f, f + 3);
+                std::memcpy(f, base + ot, 8);  uv.insert(uv.end(), f, f + 2);
+            }
+            int64_t count = jaccessors.at((size_t)idx_accessor).at("count").as_int(0);
+            int32_t material = (int32_t)prim.at("material").as_int(-1);
+            for (int64_t i = 0; i < count / 3; i++) mat.push_back(material);     // Scene.cu:172-175
+        }
+        size_t n_tris = pos.size() / 9;
+        if (pos.size() % 9 != 0 || mat.size() < n_tris)
+            throw UnsupportedError("index bufferView / accessor count mismatch (Scene.cu:301 would read out of bounds)");
+        for (size_t t = 0; t < n_tris; t++) {
+            int32_t m = mat[t];
+            if (m < 0 || (size_t)m >= fresh.materials.size())
+                throw UnsupportedError("primitive without a valid material (the kernel would index m_Material out of bounds)");
+        }
+        fresh.set_geometry(pos.data(), nrm.data(), uv.data(), mat.data(), (int32_t)n_tris);
+    }
+    for (const drt_material &m : fresh.materials)
+        if (m.albedo_tex >= (int32_t)fresh.textures.size())
+            throw UnsupportedError("baseColorTexture.index beyond the image list (used as image index, Scene.cu:79)");
+
+    triangles = std::move(fresh.triangles);
+    materials = std::move(fresh.materials);
+    textures = std::move(fresh.textures);
+    meshes = std::move(fresh.meshes);
+    nodes.clear();
+    ++revision;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Binned-SAH builder (BVHBuilder.cu)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Extent { V3 lo, size; };
+
+// getAbsoluteExtent (BVHBuilder.cuh:48-95): returns min and (max - min)
+template <class Index>
+Extent absolute_extent(const std::vector<drt_triangle> &tris, Index first, Index last, const int32_t *indirect) {
+    V3 lo = v3(FLT_MAX, FLT_MAX, FLT_MAX), hi = v3(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+    for (Index i = first; i < last; i++) {
+        const drt_triangle &t = tris[(size_t)(indirect ? indirect[i] : i)];
+        for (int k = 0; k < 3; k++) {
+            const float *p = t.vertex[k].position;
+            lo.x = fminf(lo.x, p[0]); lo.y = fminf(lo.y, p[1]); lo.z = fminf(lo.z, p[2]);
+            hi.x = fmaxf(hi.x, p[0]); hi.y = fmaxf(hi.y, p[1]); hi.z = fmaxf(hi.z, p[2]);
+        }
+    }
+    return Extent{ lo, v3(hi.x - lo.x, hi.y - lo.y, hi.z - lo.z) };
+}
+
+drt_bvh_node fresh_node() {             // BVHNode.cuh:19-25, Bounds.cuh:12-13
+    drt_bvh_node n;
+    std::memset(&n, 0, sizeof n);
+    n.bmin[0] = n.bmin[1] = n.bmin[2] = FLT_MAX;
+    n.bmax[0] = n.bmax[1] = n.bmax[2] = -FLT_MAX;
+    n.child1 = n.child2 = -1;
+    n.prim_count = 0;
+    n.prim_start = -1;
+    return n;
+}
+
+void set_bounds(drt_bvh_node &n, const Extent &e) {      // Bounds3f(minextent, minextent + extent)
+    st(n.bmin, e.lo);
+    st(n.bmax, e.lo + e.size);
+}
+
+float surface_area(const float *lo, const float *hi) {   // Bounds.cu:4-10
+    float planex = 2 * (hi[2] - lo[2]) * (hi[1] - lo[1]);
+    float planey = 2 * (hi[2] - lo[2]) * (hi[0] - lo[0]);
+    float planez = 2 * (hi[0] - lo[0]) * (hi[1] - lo[1]);
+    return planex + planey + planez;
+}
+
+float node_area(const drt_bvh_node &n) { return n.prim_count == 0 ? 0.f : surface_area(n.bmin, n.bmax); }   // BVHNode.cuh:29-35
+
+// The reference truncates a float SAH cost into an int (BVHBuilder.cu:284); it is an x86-64 build, where
+// cvttss2si turns NaN / out-of-range into INT_MIN.
+int truncate_like_x86(float f) {
+    if (!(f > -2147483904.0f && f < 2147483648.0f)) return INT_MIN;
+    return (int)f;
+}
+
+struct Builder {
+    std::vector<drt_triangle> &tris;
+    int32_t bins;
+    std::vector<int32_t> left_ids, right_ids;
+
+    // binToShallowNodes (BVHBuilder.cu:216-255): classify, take bounds, no reordering
+    void classify(drt_bvh_node &left, drt_bvh_node &right, float plane, int axis, int32_t first, int32_t last) {
+        left_ids.clear(); right_ids.clear();
+        for (int32_t i = first; i < last; i++)
+            (tris[(size_t)i].centroid[axis] < plane ? left_ids : right_ids).push_back(i);
+        left.prim_count = (int32_t)left_ids.size();
+        set_bounds(left, absolute_extent<size_t>(tris, 0, left_ids.size(), left_ids.data()));
+        right.prim_count = (int32_t)right_ids.size();
+        set_bounds(right, absolute_extent<size_t>(tris, 0, right_ids.size(), right_ids.data()));
+    }
+
+    // binToNodes (BVHBuilder.cu:175-214).  std::partition on a vector iterator takes libstdc++'s
+    // bidirectional algorithm; calling it here reproduces the reference's swap sequence and so the
+    // in-leaf triangle order (which decides ties at equal hit distance).
+    void split(drt_bvh_node &left, drt_bvh_node &right, float plane, int axis, int32_t first, int32_t last) {
+        auto mid_it = std::partition(tris.begin() + first, tris.begin() + last,
+                                     [plane, axis](const drt_triangle &t) { return t.centroid[axis] < plane; });
+        int32_t mid = (int32_t)(mid_it - tris.begin());
+        left.prim_start = first;
+        left.prim_count = mid - first;
+        set_bounds(left, absolute_extent<int32_t>(tris, left.prim_start, left.prim_start + left.prim_count, nullptr));
+        right.prim_start = mid;
+        right.prim_count = last - mid;
+        set_bounds(right, absolute_extent<int32_t>(tris, right.prim_start, right.prim_start + right.prim_count, nullptr));
+    }
+
+    // makePartition (BVHBuilder.cu:257-346)
+    void make_partition(int32_t first, int32_t last, drt_bvh_node &left_out, drt_bvh_node &right_out) {
+        Extent ext = absolute_extent<int32_t>(tris, first, last, nullptr);
+        drt_bvh_node parent = fresh_node();
+        set_bounds(parent, ext);
+        const float parent_area = surface_area(parent.bmin, parent.bmax);
+        const float lo[3] = { ext.lo.x, ext.lo.y, ext.lo.z }, size[3] = { ext.size.x, ext.size.y, ext.size.z };
+        drt_bvh_node left = fresh_node(), right = fresh_node();
+        int lowest = INT_MAX, best_axis = 0;
+        float best_plane = 0;
+        for (int axis = 0; axis < 3; axis++) {
+            float delta = size[axis] / bins;
+            for (int i = 1; i < bins; i++) {
+                float plane = lo[axis] + (i * delta);
+                classify(left, right, plane, axis, first, last);
+                // int cost = trav_cost + (SA_l / SA_p) * n_l * rayint_cost + (SA_r / SA_p) * n_r * rayint_cost
+                float fcost = 1 + ((node_area(left) / parent_area) * left.prim_count * 2)
+                                + ((node_area(right) / parent_area) * right.prim_count * 2);
+                int cost = truncate_like_x86(fcost);
+                if (cost < lowest) { lowest = cost; best_axis = axis; best_plane = plane; }   // strict <: first wins
+            }
+        }
+        split(left_out, right_out, best_plane, best_axis, first, last);
+    }
+};
+
+}  // namespace
+
+void HostScene::build_bvh(int32_t target_leaf_prims, int32_t bin_count) {
+    if (bin_count < 2) throw std::invalid_argument("bin_count must be >= 2");
+    nodes.clear();
+    ++revision;
+    const int32_t n = (int32_t)triangles.size();
+    drt_bvh_node root = fresh_node();
+    set_bounds(root, absolute_extent<int32_t>(triangles, 0, n, nullptr));
+    root.prim_start = 0;
+    root.prim_count = n;
+    if (n <= target_leaf_prims) {                        // BVHBuilder.cu:34-43
+        root.is_leaf = 1;
+        nodes.push_back(root);
+        return;
+    }
+    std::vector<drt_triangle> work = triangles;          // reordered copy, committed on success
+    std::vector<drt_bvh_node> out;
+    out.reserve((size_t)2 * (size_t)n + 2);
+    Builder b{ work, bin_count, {}, {} };
+    std::vector<int32_t> todo;                           // -1 = the detached root (appended last, BVHBuilder.cu:85)
+    todo.push_back(-1);
+    while (!todo.empty()) {
+        int32_t cur = todo.back();
+        todo.pop_back();
+        drt_bvh_node node = cur < 0 ? root : out[(size_t)cur];
+        if (node.prim_count <= target_leaf_prims) {      // BVHBuilder.cu:54-59
+            node.is_leaf = 1;
+        } else {
+            drt_bvh_node l = fresh_node(), r = fresh_node();
+            b.make_partition(node.prim_start, node.prim_start + node.prim_count, l, r);
+            if (l.prim_count == 0 || r.prim_count == 0)
+                throw BvhError("degenerate partition: every candidate plane leaves one side empty "
+                               "(BVHBuilder.cu:49-83 never terminates on this input)");
+            if (todo.size() + 2 > 512)                   // MAX_STACK_SIZE, BVHBuilder.cu:24
+                throw BvhError("build stack deeper than the reference's 512-entry stack");
+            out.push_back(l); node.child1 = (int32_t)out.size() - 1;
+            out.push_back(r); node.child2 = (int32_t)out.size() - 1;
+            todo.push_back(node.child1);                 // right child is built first (stack), BVHBuilder.cu:81-82
+            todo.push_back(node.child2);
+        }
+        if (cur < 0) root = node; else out[(size_t)cur] = node;
+    }
+    out.push_back(root);
+    triangles.swap(work);
+    nodes.swap(out);
+}
+
+int32_t HostScene::bvh_depth() const {
+    if (nodes.empty()) return 0;
+    int32_t depth = 0;
+    std::vector<std::pair<int32_t, int32_t>> todo{ { (int32_t)nodes.size() - 1, 1 } };
+    while (!todo.empty()) {
+        auto [i, d] = todo.back();
+        todo.pop_back();
+        depth = std::max(depth, d);
+        const drt_bvh_node &n = nodes[(size_t)i];
+        if (!n.is_leaf) { todo.push_back({ n.child1, d + 1 }); todo.push_back({ n.child2, d + 1 }); }
+    }
+    return depth;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device packing
+// ---------------------------------------------------------------------------------------------
+PackedScene HostScene::pack() const {
+    if (nodes.empty()) throw std::invalid_argument("scene has no BVH: call build_bvh first (EditorLayer.cpp:52-55)");
+    PackedScene ps;
+    ps.depth = bvh_depth();
+    const size_t n_nodes = nodes.size();
+    std::vector<uint32_t> ref(n_nodes, kNoNode);
+    for (size_t i = 0; i < n_nodes; i++) {
+        const drt_bvh_node &n = nodes[i];
+        if (n.is_leaf) {
+            ref[i] = kLeafBit | (uint32_t)ps.leaves.size();
+            ps.leaves.push_back(LeafRange{ n.prim_start, n.prim_count });
+            ps.max_leaf = std::max(ps.max_leaf, n.prim_count);
+        } else {
+            ref[i] = (uint32_t)ps.inner.size();
+            ps.inner.emplace_back();
+        }
+    }
+    for (size_t i = 0; i < n_nodes; i++) {
+        const drt_bvh_node &n = nodes[i];
+        if (n.is_leaf) continue;
+        InnerNode &rec = ps.inner[ref[i]];
+        const drt_bvh_node &a = nodes[(size_t)n.child1], &b = nodes[(size_t)n.child2];
+        std::memcpy(rec.c1min, a.bmin, 12); std::memcpy(rec.c1max, a.bmax, 12);
+        std::memcpy(rec.c2min, b.bmin, 12); std::memcpy(rec.c2max, b.bmax, 12);
+        rec.c1ref = ref[(size_t)n.child1];
+        rec.c2ref = ref[(size_t)n.child2];
+        rec._pad[0] = rec._pad[1] = 0;
+    }
+    const drt_bvh_node &root = nodes.back();             // root = last node (TraceRay.cu:20)
+    ps.root_ref = ref[n_nodes - 1];
+    std::memcpy(ps.root_min, root.bmin, 12);
+    std::memcpy(ps.root_max, root.bmax, 12);
+
+    ps.tri_hot.resize(triangles.size());
+    ps.tri_cold.resize(triangles.size());
+    for (size_t i = 0; i < triangles.size(); i++) {
+        const drt_triangle &t = triangles[i];
+        V3 p0 = ld(t.vertex[0].position);
+        st(ps.tri_hot[i].v0, p0);
+        st(ps.tri_hot[i].e1, ld(t.vertex[1].position) - p0);    // Intersection.cu:8
+        st(ps.tri_hot[i].e2, ld(t.vertex[2].position) - p0);    // Intersection.cu:9
+        std::memcpy(ps.tri_hot[i].fn, t.face_normal, 12);
+        for (int k = 0; k < 3; k++) { ps.tri_cold[i].uv[k][0] = t.vertex[k].uv[0]; ps.tri_cold[i].uv[k][1] = t.vertex[k].uv[1]; }
+        ps.tri_cold[i].material = t.material;
+        ps.tri_cold[i]._pad = 0;
+    }
+    for (const drt_material &m : materials) {
+        MatDev d;
+        std::memcpy(d.albedo, m.albedo, 12);
+        d.tex = m.albedo_tex;
+        ps.mats.push_back(d);
+    }
+    for (const HostTexture &t : textures) {
+        TexDev d;
+        d.width = t.width; d.height = t.height; d.comps = t.components;
+        d.offset = (uint32_t)ps.texels.size();
+        ps.texels.insert(ps.texels.end(), t.texels.begin(), t.texels.end());
+        ps.texels.resize(ps.texels.size() + (size_t)(t.width + 1) * (size_t)t.components, 0);
+        while (ps.texels.size() % 16) ps.texels.push_back(0);
+        ps.texs.push_back(d);
+        if (t.components == 4) ps.any_alpha_texture = true;
+    }
+    return ps;
+}
+
+}  // namespace drt

@@ -1,0 +1,185 @@
+/*
+ * drt.h -- C ABI of the MI355X-native DustRayTracer path-tracing core.
+ *
+ * One shared library (dustraytracer_amd/libdrt_hip.so) exports exactly these
+ * symbols.  They are what a binding for the reference's Renderer / Scene /
+ * BVHBuilder / Camera classes needs (include/DustRayTracer.hpp is that binding
+ * for C++; INTEGRATION.md shows the editor-side change).  Plain pointers and
+ * sizes only.  Citations are relative to /root/reference/DustRayTracer/src/.
+ *
+ * Error model (replaces Editor/Common/CudaCommon.cu:4-13, which prints,
+ * cudaDeviceReset()s and exit(99)s): every call returns DRT_OK (0) or a
+ * negative drt_status; drt_last_error() returns a thread-local message.
+ * Nothing in the library ever calls exit().
+ *
+ * There is NO CPU fallback: a call that needs the GPU fails with
+ * DRT_ERR_DEVICE when no gfx950 device is usable.
+ */
+#ifndef DRT_H
+#define DRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRT_ABI_VERSION 1
+
+typedef enum {
+    DRT_OK = 0,
+    DRT_ERR_INVALID = -1,      /* bad argument / bad handle state */
+    DRT_ERR_IO = -2,           /* file missing or unreadable */
+    DRT_ERR_PARSE = -3,        /* glTF / PNG content not understood */
+    DRT_ERR_UNSUPPORTED = -4,  /* valid input outside the reference loader's subset */
+    DRT_ERR_DEVICE = -5,       /* HIP error, no device, out of device memory */
+    DRT_ERR_BVH = -6           /* builder cannot terminate on this input (the reference hangs) */
+} drt_status;
+
+/* ---- PODs mirroring the reference's public data ---- */
+
+/* Core/Scene/RendererSettings.h:4-35 (bools widened to int32 for a stable ABI). */
+typedef struct drt_settings {
+    int32_t gamma_correction;      /* :22 default 1 */
+    int32_t tone_mapping;          /* :23 default 1 */
+    int32_t enable_sunlight;       /* :24 default 0 */
+    int32_t max_samples;           /* :25 default 500; Render is a no-op once sample_count == max_samples */
+    int32_t ray_bounce_limit;      /* :26 default 2; the path loop runs i = 0..limit inclusive */
+    int32_t render_mode;           /* :27 0 NORMALMODE, 1 DEBUGMODE */
+    int32_t debug_mode;            /* :28 0 ALBEDO 1 NORMAL 2 BARYCENTRIC 3 UVS 4 MESHBVH 5 WORLDBVH */
+    float   sunlight_dir[2];       /* :29 */
+    float   sunlight_color[3];     /* :30 */
+    float   sunlight_intensity;    /* :31 */
+    float   sky_color[3];          /* :32 */
+    float   sky_intensity;         /* :34 */
+} drt_settings;
+
+/* Core/Scene/Camera.cuh:30-47: the fields the kernel reads (Camera.cu:82-123). */
+typedef struct drt_camera {
+    float exposure;                /* :32 */
+    float vfov_rad;                /* :33 */
+    float defocus_angle;           /* :37 */
+    float focus_dist;              /* :38 */
+    float position[3];             /* :43 m_Position */
+    float forward[3];              /* :44 m_Forward_dir */
+} drt_camera;
+
+/* Core/Scene/Vertex.cuh:4-12 (32 bytes) */
+typedef struct drt_vertex { float position[3]; float normal[3]; float uv[2]; } drt_vertex;
+
+/* Core/Scene/Triangle.cuh:7-19 (128 bytes, same field offsets as the reference struct) */
+typedef struct drt_triangle {
+    float centroid[3]; float _pad0;
+    drt_vertex vertex[3];
+    float face_normal[3];
+    int32_t material;
+} drt_triangle;
+
+/* Core/BVH/BVHNode.cuh:14-44 (44 bytes). The root is the LAST node (BVHBuilder.cu:85). */
+typedef struct drt_bvh_node {
+    uint8_t is_leaf; uint8_t _pad0[3];
+    float bmin[3], bmax[3];
+    int32_t child1, child2;
+    int32_t prim_count, prim_start;
+} drt_bvh_node;
+
+/* Core/Scene/Material.cuh:4-23 (44 bytes); the kernel reads albedo + albedo_tex only (RayGen.cuh:112-117). */
+typedef struct drt_material {
+    float albedo[3];
+    float emissive[3];
+    int32_t albedo_tex;
+    float roughness;
+    uint8_t transmission; uint8_t _pad0[3];
+    float refractive_index;
+    uint8_t metallic; uint8_t _pad1[3];
+} drt_material;
+
+/* Core/Scene/Mesh.cuh:8-18 */
+typedef struct drt_mesh { int32_t primitives_offset; int32_t tris_count; } drt_mesh;
+
+typedef struct drt_texture_info { int32_t width, height, components; } drt_texture_info;
+
+/* Exact device-side work counters for one render call (drt_renderer_set_counting). */
+typedef struct drt_counters {
+    uint64_t samples, rays, node_visits, inner_visits, tri_tests, hits_textured, hits_flat,
+             shadow_rays, inner_visits_shadow, tri_tests_shadow;
+} drt_counters;
+
+typedef struct drt_scene drt_scene;         /* replaces struct Scene, Core/Scene/Scene.cuh:41-57 */
+typedef struct drt_renderer drt_renderer;   /* replaces class Renderer, Core/Renderer.hpp:14-47 */
+
+/* ---- library ---- */
+int         drt_abi_version(void);
+const char *drt_last_error(void);
+int         drt_device_count(void);                       /* usable HIP devices, 0 when none */
+void        drt_default_settings(drt_settings *out);      /* RendererSettings.h:22-34 */
+void        drt_default_camera(drt_camera *out);          /* Camera.cuh:32-46 + EditorLayer.cpp:35-40 */
+
+/* ---- Scene: host-side load + BVH build (Scene.cu:181-317, BVHBuilder.cu:11-92) ---- */
+drt_scene *drt_scene_create(void);
+void       drt_scene_destroy(drt_scene *s);                                   /* Scene::~Scene, Scene.cu:319-344 */
+int        drt_scene_load_gltf(drt_scene *s, const char *path);               /* Scene::loadGLTFmodel */
+/* Programmatic alternative to a file: de-indexed streams, 3 vertices per triangle. */
+int        drt_scene_set_geometry(drt_scene *s, const float *positions, const float *normals, const float *uvs,
+                                  const int32_t *material_ids, int32_t n_tris);
+int        drt_scene_add_material(drt_scene *s, const float albedo[3], int32_t albedo_tex);
+int        drt_scene_add_texture(drt_scene *s, const uint8_t *texels, int32_t width, int32_t height, int32_t components);
+int        drt_scene_build_bvh(drt_scene *s, int32_t target_leaf_prims, int32_t bin_count);  /* BVHBuilder::buildIterative */
+int32_t    drt_scene_triangle_count(const drt_scene *s);                      /* m_PrimitivesBuffer.size() */
+int32_t    drt_scene_node_count(const drt_scene *s);                          /* m_BVHNodes.size() */
+int32_t    drt_scene_material_count(const drt_scene *s);
+int32_t    drt_scene_texture_count(const drt_scene *s);
+int32_t    drt_scene_mesh_count(const drt_scene *s);
+int32_t    drt_scene_bvh_depth(const drt_scene *s);                           /* levels, 0 when no BVH */
+int        drt_scene_get_triangles(const drt_scene *s, drt_triangle *out, int32_t cap);
+int        drt_scene_get_nodes(const drt_scene *s, drt_bvh_node *out, int32_t cap);
+int        drt_scene_get_materials(const drt_scene *s, drt_material *out, int32_t cap);
+int        drt_scene_get_meshes(const drt_scene *s, drt_mesh *out, int32_t cap);
+int        drt_scene_get_texture_info(const drt_scene *s, int32_t index, drt_texture_info *out);
+int        drt_scene_get_texture_texels(const drt_scene *s, int32_t index, uint8_t *out, size_t cap);
+
+/* ---- Renderer (Core/Renderer.hpp:14-47, Core/Renderer.cu) ---- */
+drt_renderer *drt_renderer_create(int32_t device);                            /* Renderer::Renderer */
+void          drt_renderer_destroy(drt_renderer *r);                          /* Renderer::~Renderer */
+int           drt_renderer_resize(drt_renderer *r, uint32_t width, uint32_t height);   /* ResizeBuffer: no-op for equal size, else realloc + reset */
+int           drt_renderer_set_settings(drt_renderer *r, const drt_settings *s);       /* writes m_RendererSettings (caller resets, EditorLayer.cpp:241-277) */
+int           drt_renderer_get_settings(const drt_renderer *r, drt_settings *out);
+/* Render: ONE frame index, blocking, returns kernel ms in *delta_ms (Renderer.cu:80-117). No-op when sample_count == max_samples. */
+int           drt_renderer_render(drt_renderer *r, const drt_camera *cam, const drt_scene *scene, float *delta_ms);
+/* spp batch: frames sample_count .. sample_count+n_frames-1 in one launch; per-pixel sum order ((a+c_f)+c_f+1)+... is kept,
+ * so the result is bit-identical to n_frames drt_renderer_render calls.  Clamped so that sample_count never passes max_samples. */
+int           drt_renderer_render_batch(drt_renderer *r, const drt_camera *cam, const drt_scene *scene,
+                                        uint32_t n_frames, float *delta_ms);
+int           drt_renderer_reset(drt_renderer *r);                            /* resetAccumulationBuffer: zero + sample_count = 1 */
+uint32_t      drt_renderer_width(const drt_renderer *r);                      /* getBufferWidth */
+uint32_t      drt_renderer_height(const drt_renderer *r);                     /* getBufferHeight */
+uint32_t      drt_renderer_sample_count(const drt_renderer *r);               /* getSampleCount == m_FrameIndex (starts at 1) */
+/* Framebuffer out (replaces the GL RGBA32F texture of Renderer.cu:48,70; row 0 = bottom, alpha = 1).
+ * Sharded renderers hold local_rows rows; unsharded ones hold all of them. */
+uint32_t      drt_renderer_local_rows(const drt_renderer *r);
+int           drt_renderer_read_rgba32f(drt_renderer *r, float *dst, size_t dst_floats);   /* width*local_rows*4 */
+int           drt_renderer_read_accum(drt_renderer *r, float *dst, size_t dst_floats);     /* width*local_rows*3 */
+void         *drt_renderer_device_rgba(drt_renderer *r);                      /* device float4[width*local_rows] */
+void         *drt_renderer_device_accum(drt_renderer *r);                     /* device float3[width*local_rows] */
+
+/* ---- multi-GPU sharding (new; the reference is single-device) ---- */
+/* This renderer owns the rows y with (y / stripe_rows) % world == rank, stored compactly in stripe order.
+ * RNG seeds use the GLOBAL pixel index, so any partition reproduces the single-device image bit for bit. */
+int           drt_renderer_set_shard(drt_renderer *r, uint32_t stripe_rows, uint32_t rank, uint32_t world);
+/* Use caller-owned device buffers (e.g. torch tensors) instead of internal ones; NULL restores internal. */
+int           drt_renderer_bind_buffers(drt_renderer *r, void *device_accum, void *device_rgba);
+int           drt_renderer_set_stream(drt_renderer *r, void *hip_stream);     /* hipStream_t, NULL = default stream */
+int           drt_renderer_set_counting(drt_renderer *r, int32_t enable);     /* exact work counters (slower kernel) */
+int           drt_renderer_get_counters(drt_renderer *r, drt_counters *out);
+int           drt_renderer_kernel_info(const drt_renderer *r, char *buf, size_t cap);  /* name/variant of the last kernel */
+/* rank-0 side of the gather: `gathered` = world shards of padded_rows rows each (as written by the ranks' device_rgba),
+ * `image` = full width*height float4.  Runs on `hip_stream`. */
+int           drt_assemble_shards(const void *gathered, void *image, uint32_t width, uint32_t height,
+                                  uint32_t stripe_rows, uint32_t world, uint32_t padded_rows, void *hip_stream);
+uint32_t      drt_shard_rows(uint32_t height, uint32_t stripe_rows, uint32_t rank, uint32_t world);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,26 @@
+"""Shared test configuration: fixture scenes, benchmark poses, helpers."""
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODELS = os.path.join(ROOT, "models")
+
+# name -> (file, camera position, camera forward, path depth used by BASELINE.json's configs)
+SCENES = {
+    "cornell_box": ("cornell_box.glb", (3.6, 1.25, 0.0), (-1.0, 0.0, 0.0), 8),
+    "suzanne_plane": ("suzanne_plane.glb", (0.0, 1.2, 4.5), (0.0, -0.15, -1.0), 2),
+    "dense_monkey": ("dense_monkey.glb", (0.0, 0.0, 2.7), (0.0, 0.0, -1.0), 2),
+    "room": ("room.glb", (0.0, 1.4, 2.0), (0.0, 0.0, -1.0), 16),
+    "uv_texture_test": (os.path.join("test", "UVtextureTest.glb"), (0.0, 1.0, 4.0), (0.0, -0.1, -1.0), 3),
+    "bvh_split_test": (os.path.join("test", "bvhsplitTest.glb"), (0.0, 2.0, 5.0), (0.0, -0.2, -1.0), 2),
+    "multi_material": (os.path.join("test", "multiMaterialMeshTest.glb"), (0.0, 2.0, 5.0), (0.0, -0.2, -1.0), 2),
+}
+
+
+def scene_path(name):
+    return os.path.join(MODELS, SCENES[name][0])
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)

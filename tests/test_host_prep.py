@@ -1,0 +1,141 @@
+"""Host prep of the product (C++ glTF flattening, PNG decode, binned-SAH builder inside libdrt_hip.so)
+against the oracle's independent restatement (Python GLB reader + Pillow PNG + C builder).
+No GPU needed: these entry points never touch HIP.  Everything is bit-exact."""
+import numpy as np
+import pytest
+
+import oracle
+from tests.scenes import SCENES, bits, scene_path
+
+drt = pytest.importorskip("dustraytracer_amd")
+
+
+def load_both(name, leaf=20, bins=8):
+    sc = drt.Scene()
+    sc.loadGLTFmodel(scene_path(name))
+    osc = oracle.Scene.load_glb(scene_path(name))
+    return sc, osc
+
+
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_flattened_triangles_match_oracle(name):
+    sc, osc = load_both(name)
+    tris = sc.m_PrimitivesBuffer
+    assert len(tris) == len(osc.tris) and len(tris) > 0
+    assert np.array_equal(bits(tris["centroid"]), bits(osc.tris["centroid"]))
+    assert np.array_equal(bits(tris["vertex"]["position"]), bits(osc.tris["p"]))
+    assert np.array_equal(bits(tris["vertex"]["normal"]), bits(osc.tris["n"]))
+    assert np.array_equal(bits(tris["vertex"]["uv"]), bits(osc.tris["uv"]))
+    assert np.array_equal(bits(tris["face_normal"]), bits(osc.tris["face_n"]))
+    assert np.array_equal(tris["material"], osc.tris["material"])
+    mats = sc.m_Material
+    assert len(mats) == osc.n_mats
+    assert np.array_equal(bits(mats["albedo"]), bits(osc.mats["albedo"][: osc.n_mats]))
+    assert np.array_equal(mats["albedo_tex"], osc.mats["albedo_tex"][: osc.n_mats])
+    meshes = sc.m_Meshes
+    assert [(int(m["primitives_offset"]), int(m["tris_count"])) for m in meshes] == list(osc.meshes)
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "dense_monkey", "uv_texture_test"])
+def test_png_decoder_matches_pillow(name):
+    sc, osc = load_both(name)
+    texs = sc.m_Textures
+    assert len(texs) == len(osc.textures) and len(texs) > 0
+    for mine, ref in zip(texs, osc.textures):
+        assert mine.shape == ref.shape
+        assert np.array_equal(mine, ref)
+
+
+def test_uv_texture_test_has_alpha_channel():
+    sc, _ = load_both("uv_texture_test")
+    comps = sorted(t.shape[2] for t in sc.m_Textures)
+    assert 4 in comps            # the only fixture that exercises AnyHit's alpha cut-out
+    alpha = [t for t in sc.m_Textures if t.shape[2] == 4][0][..., 3]
+    assert alpha.min() < 255 and alpha.max() == 255
+
+
+@pytest.mark.parametrize("name,leaf,bins", [(n, 20, 8) for n in sorted(SCENES)] +
+                         [("suzanne_plane", 6, 8), ("suzanne_plane", 4, 4), ("room", 1, 16), ("dense_monkey", 8, 12)])
+def test_bvh_matches_oracle(name, leaf, bins):
+    sc, osc = load_both(name)
+    b = drt.BVHBuilder()
+    b.m_TargetLeafPrimitivesCount, b.m_BinCount = leaf, bins
+    try:
+        osc.build_bvh(leaf, bins)
+    except RuntimeError:
+        with pytest.raises(drt.DrtError) as e:
+            b.buildIterative(sc)
+        assert e.value.code == drt.ERR_BVH        # the reference never terminates on this input
+        return
+    b.buildIterative(sc)
+    nodes, onodes = sc.m_BVHNodes, osc.nodes
+    assert len(nodes) == len(onodes)
+    assert np.array_equal(nodes["is_leaf"].astype(np.int32), onodes["is_leaf"])
+    for f in ("child1", "child2", "prim_count", "prim_start"):
+        assert np.array_equal(nodes[f], onodes[f]), f
+    assert np.array_equal(bits(nodes["bmin"]), bits(onodes["bmin"]))
+    assert np.array_equal(bits(nodes["bmax"]), bits(onodes["bmax"]))
+    # triangles were reordered identically (libstdc++ std::partition swap sequence)
+    assert np.array_equal(bits(sc.m_PrimitivesBuffer["centroid"]), bits(osc.tris["centroid"]))
+    assert sc.bvh_depth == oracle.tree_depth(onodes)
+
+
+def test_bvh_shape_of_baseline_scenes():
+    """Node counts / depths measured by SURVEY.md 8(a) T1 with the reference's own builder sources."""
+    expect = {"cornell_box": (34, 5, 3), "room": (330, 51, 8), "suzanne_plane": (970, 137, 10), "dense_monkey": (15744, 2347, 15)}
+    for name, (tris, nodes, depth) in expect.items():
+        sc, _ = load_both(name)
+        b = drt.BVHBuilder()
+        b.m_TargetLeafPrimitivesCount, b.m_BinCount = 20, 8
+        b.buildIterative(sc)
+        assert (len(sc.m_PrimitivesBuffer), len(sc.m_BVHNodes), sc.bvh_depth) == (tris, nodes, depth), name
+        n = sc.m_BVHNodes
+        root = n[-1]                                   # root is the last node (BVHBuilder.cu:85)
+        assert root["prim_start"] == 0 and root["prim_count"] == tris
+        leaves = n[n["is_leaf"] == 1]
+        assert leaves["prim_count"].sum() == tris and leaves["prim_count"].max() <= 20
+
+
+def test_small_scene_becomes_single_leaf():
+    sc = drt.Scene()
+    sc.addMaterial((0.5, 0.5, 0.5))
+    pos = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], np.float32)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), 3)[None]
+    sc.setGeometry(pos, nrm, np.zeros((1, 6), np.float32), [0])
+    b = drt.BVHBuilder()
+    b.buildIterative(sc)
+    n = sc.m_BVHNodes
+    assert len(n) == 1 and n[0]["is_leaf"] == 1 and n[0]["prim_count"] == 1     # BVHBuilder.cu:34-43
+    t = sc.m_PrimitivesBuffer[0]
+    assert np.allclose(t["face_normal"], [0, 0, 1]) and np.allclose(t["centroid"], [1 / 3, 1 / 3, 0])
+
+
+def test_loader_errors_are_reported_not_fatal(tmp_path):
+    sc = drt.Scene()
+    with pytest.raises(drt.DrtError) as e:
+        sc.loadGLTFmodel(str(tmp_path / "missing.glb"))
+    assert e.value.code == drt.ERR_IO
+    bad = tmp_path / "bad.glb"
+    bad.write_bytes(b"glTF" + b"\x02\x00\x00\x00" + b"\x20\x00\x00\x00" + b"\x04\x00\x00\x00JSON{{{{" + b"\0" * 8)
+    with pytest.raises(drt.DrtError) as e:
+        sc.loadGLTFmodel(str(bad))
+    assert e.value.code == drt.ERR_PARSE
+    with pytest.raises(drt.DrtError) as e:
+        sc.loadGLTFmodel(str(tmp_path / "scene.gltf"))
+    assert e.value.code == drt.ERR_UNSUPPORTED
+    # a scene that failed to load keeps the handle usable
+    sc.loadGLTFmodel(scene_path("room"))
+    assert len(sc.m_PrimitivesBuffer) == 330
+
+
+def test_degenerate_bvh_input_is_an_error_not_a_hang():
+    sc = drt.Scene()
+    sc.addMaterial((1, 1, 1))
+    n = 30                                              # > leaf target, all centroids identical
+    pos = np.tile(np.array([0, 0, 0, 1, 0, 0, 0, 1, 0], np.float32), (n, 1))
+    nrm = np.tile(np.array([0, 0, 1] * 3, np.float32), (n, 1))
+    sc.setGeometry(pos, nrm, np.zeros((n, 6), np.float32), np.zeros(n, np.int32))
+    b = drt.BVHBuilder()
+    with pytest.raises(drt.DrtError) as e:
+        b.buildIterative(sc)
+    assert e.value.code == drt.ERR_BVH
