@@ -24,6 +24,32 @@ LIB_PATH = os.path.join(_HERE, "libdrt_hip.so")
 if not os.path.exists(LIB_PATH):
     raise ImportError("dustraytracer_amd: %s is missing -- the HIP extension must be built "
                       "(make -C dustraytracer_amd/csrc); there is no fallback path" % LIB_PATH)
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process.  libdrt_hip.so needs libamdhip64.so.7; PyTorch-ROCm wheels bundle
+    their own copy under the same soname.  Whichever copy is loaded first serves both, and torch
+    finds no GPU when the system copy was loaded before its own.  So when a torch wheel is installed
+    (and DRT_HIP_RUNTIME != "system") its copy is loaded first, without importing torch."""
+    import importlib.util
+    import sys
+    if os.environ.get("DRT_HIP_RUNTIME", "torch") == "system" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+_preload_hip_runtime()
 _lib = C.CDLL(LIB_PATH)
 
 

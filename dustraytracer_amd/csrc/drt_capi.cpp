@@ -170,7 +170,7 @@ int drt_scene_add_material(drt_scene *s, const float albedo[3], int32_t albedo_t
         m.albedo_tex = albedo_tex;
         m.refractive_index = 1.45f;
         s->host.materials.push_back(m);
-        ++s->host.revision;
+        s->host.revision = HostScene::next_revision();
         return (int)s->host.materials.size() - 1;
     } catch (...) { return from_exception(); }
 }
@@ -183,7 +183,7 @@ int drt_scene_add_texture(drt_scene *s, const uint8_t *texels, int32_t width, in
         t.width = width; t.height = height; t.components = components;
         t.texels.assign(texels, texels + (size_t)width * height * components);
         s->host.textures.push_back(std::move(t));
-        ++s->host.revision;
+        s->host.revision = HostScene::next_revision();
         return (int)s->host.textures.size() - 1;
     } catch (...) { return from_exception(); }
 }

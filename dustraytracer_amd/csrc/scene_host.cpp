@@ -9,6 +9,7 @@
 #include "scene_host.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <climits>
 #include <cmath>
@@ -21,6 +22,11 @@
 
 namespace drt {
 
+uint64_t HostScene::next_revision() {
+    static std::atomic<uint64_t> counter{ 0 };
+    return ++counter;
+}
+
 V3 normalize(V3 v) {
     float inv_len = 1.0f / sqrtf(dot(v, v));
     return v * inv_len;
@@ -31,7 +37,7 @@ static inline void st(float *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
 
 void HostScene::clear() {
     triangles.clear(); materials.clear(); textures.clear(); meshes.clear(); nodes.clear();
-    ++revision;
+    revision = next_revision();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -67,7 +73,7 @@ void HostScene::set_geometry(const float *pos, const float *nrm, const float *uv
     mesh.tris_count = n_tris;
     meshes.push_back(mesh);
     nodes.clear();
-    ++revision;
+    revision = next_revision();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -233,7 +239,7 @@ void HostScene::load_gltf(const char *path) {
     textures = std::move(fresh.textures);
     meshes = std::move(fresh.meshes);
     nodes.clear();
-    ++revision;
+    revision = next_revision();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -352,7 +358,7 @@ struct Builder {
 void HostScene::build_bvh(int32_t target_leaf_prims, int32_t bin_count) {
     if (bin_count < 2) throw std::invalid_argument("bin_count must be >= 2");
     nodes.clear();
-    ++revision;
+    revision = next_revision();
     const int32_t n = (int32_t)triangles.size();
     drt_bvh_node root = fresh_node();
     set_bounds(root, absolute_extent<int32_t>(triangles, 0, n, nullptr));

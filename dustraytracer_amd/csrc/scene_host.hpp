@@ -36,7 +36,8 @@ public:
     std::vector<HostTexture> textures;       // m_Textures
     std::vector<drt_mesh> meshes;            // m_Meshes
     std::vector<drt_bvh_node> nodes;         // m_BVHNodes, root last
-    uint64_t revision = 0;                   // bumped on every change; renderers re-upload when it moves
+    uint64_t revision = next_revision();     // process-wide unique stamp, renewed on every change; renderers re-upload when it moves
+    static uint64_t next_revision();
 
     void clear();
     void load_gltf(const char *path);        // throws std::runtime_error / UnsupportedError

@@ -155,7 +155,7 @@ def test_alpha_cutout_changes_the_image(renderer):
 
 
 def test_other_leaf_sizes(renderer):
-    for leaf, bins in ((4, 8), (1, 4), (64, 8)):
+    for leaf, bins in ((4, 8), (8, 4), (64, 8)):
         sc, osc = make_pair("suzanne_plane", leaf, bins)
         cam, ocam = cameras("suzanne_plane")
         s, o = settings_pair()
