@@ -146,10 +146,15 @@ class _TexInfo(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "node_visits", "inner_visits", "tri_tests",
                                            "hits_textured", "hits_flat", "shadow_rays", "inner_visits_shadow",
-                                           "tri_tests_shadow")]
+                                           "tri_tests_shadow")] + [("phase_execs", C.c_uint64 * 4), ("phase_lanes", C.c_uint64 * 4)]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+        return {n: int(getattr(self, n)) for n, t in self._fields_ if t is C.c_uint64}
+
+    def phase_stats(self):
+        """wave_queue kernel: (executions, mean active lanes) of the T, N, S, R phases."""
+        return {k: (int(self.phase_execs[i]), self.phase_lanes[i] / max(int(self.phase_execs[i]), 1))
+                for i, k in enumerate("TNSR")}
 
     def algorithmic_bytes(self):
         """40 B/sample + 56 B/interior visit + 36 B/triangle test + 60|32 B/shaded hit (+ shadow terms)."""

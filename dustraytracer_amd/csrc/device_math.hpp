@@ -59,6 +59,18 @@ DRT_DEV f3 random_unit_sphere_vec3(uint32_t &seed) {                            
         if ((len * len) < 1) return p;
     }
 }
+// One trip of randomUnitSphereVec3's loop (Random.cu:50-58): candidate p and whether the loop returns it.
+// The reference accepts when  len*len < 1  with len = sqrtf(dot(p,p)).  For every non-negative float d (and
+// inf, NaN)  fl(fl(sqrt(d))^2) < 1  <=>  d < 1  (checked exhaustively over all 2^31 values,
+// tests/test_oracle_kat.py::test_sphere_accept_shortcut), so the sqrt and the square are not computed.
+// (float)seed / 2^32 * 2 - 1 is written as (float)seed * 2^-31 - 1: both scalings are exact.
+DRT_DEV bool random_unit_sphere_try(uint32_t &seed, f3 &p) {
+    seed = pcg_hash(seed); float x = (float)seed * 0x1p-31f - 1.f;
+    seed = pcg_hash(seed); float y = (float)seed * 0x1p-31f - 1.f;
+    seed = pcg_hash(seed); float z = (float)seed * 0x1p-31f - 1.f;
+    p = normalize(mk3(x, y, z));
+    return dot(p, p) < 1.0f;
+}
 DRT_DEV f2 random_in_unit_disk(uint32_t &seed) {                                                  // :60-66
     for (;;) {
         f2 p;
@@ -105,6 +117,25 @@ DRT_DEV bool tri_intersect(const Ray &ray, f3 v0, f3 e1, f3 e2, float &t_out, f3
         return true;
     }
     return false;
+}
+
+// Same test, straight-line: every quantity is computed, the four rejections are combined at the end.
+// A rejected lane may have divided by a tiny or zero det; its u, v, t are then garbage and never used.
+// NaN behaves as in the branchy form: comparisons with NaN are false, so only `t > eps` rejects it.
+DRT_DEV bool tri_intersect_flat(const Ray &ray, f3 v0, f3 e1, f3 e2, float &t, float &u, float &v) {
+    f3 pvec = cross(ray.dir, e2);
+    float det = dot(e1, pvec);
+    bool ok = !((det > -DRT_TRIANGLE_EPSILON) & (det < DRT_TRIANGLE_EPSILON));
+    float inv_det = 1.0f / det;
+    f3 tvec = ray.orig - v0;
+    u = inv_det * dot(tvec, pvec);
+    ok = ok & !((u < 0.0f) | (u > 1.0f));
+    f3 qvec = cross(tvec, e1);
+    v = inv_det * dot(ray.dir, qvec);
+    ok = ok & !((v < 0.0f) | (u + v > 1.0f));
+    t = inv_det * dot(e2, qvec);
+    ok = ok & (t > DRT_TRIANGLE_EPSILON);
+    return ok;
 }
 
 // ---- Shaders/RayGen.cuh:23-61 ----

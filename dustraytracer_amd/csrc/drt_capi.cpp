@@ -7,8 +7,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <stdexcept>
@@ -82,6 +84,14 @@ struct drt_renderer {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool counting = false;
     unsigned long long *counters = nullptr;
+    unsigned int *tile_counter = nullptr;     // work queue head of the wave_queue kernel
+    void *samples = nullptr;                  // wave_queue: one float4 per (pixel, frame) of a launch
+    size_t samples_bytes = 0;
+    size_t sample_budget = (size_t)1 << 30;   // frames of one batch are split so that a launch needs at most this much
+    int num_cus = 256;
+    bool use_pixel_walk = false;              // DRT_KERNEL=pixel_walk selects the first (non-persistent) kernel
+    bool scene_has_alpha = false;
+    int vote_node = 12, vote_shade = 36, vote_dir = 4;   // wave_queue phase-voting thresholds (DRT_VOTE_N/S/R override)
     const char *kernel_name = "";
     // device copy of the scene last rendered
     const drt_scene *uploaded_scene = nullptr;
@@ -262,8 +272,18 @@ drt_renderer *drt_renderer_create(int32_t device) {
     try { r = new drt_renderer(); } catch (...) { from_exception(); return nullptr; }
     r->device = device;
     drt_default_settings(&r->settings);
+    const char *which = std::getenv("DRT_KERNEL");
+    r->use_pixel_walk = which && std::strcmp(which, "pixel_walk") == 0;
+    auto env_int = [](const char *name, int dflt) { const char *v = std::getenv(name); return (v && *v) ? std::atoi(v) : dflt; };
+    r->vote_node = std::max(1, env_int("DRT_VOTE_N", r->vote_node));
+    r->vote_shade = std::max(1, env_int("DRT_VOTE_S", r->vote_shade));
+    r->vote_dir = std::max(1, env_int("DRT_VOTE_R", r->vote_dir));
+    r->sample_budget = (size_t)std::max(1, env_int("DRT_SAMPLE_MB", 1024)) << 20;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) r->num_cus = cus;
     if (hipEventCreate(&r->ev_start) != hipSuccess || hipEventCreate(&r->ev_stop) != hipSuccess ||
-        hipMalloc((void **)&r->counters, sizeof(drt_counters)) != hipSuccess) {
+        hipMalloc((void **)&r->counters, sizeof(drt_counters)) != hipSuccess ||
+        hipMalloc((void **)&r->tile_counter, sizeof(unsigned int)) != hipSuccess) {
         fail(DRT_ERR_DEVICE, "cannot create HIP events / counter buffer");
         drt_renderer_destroy(r);
         return nullptr;
@@ -278,6 +298,8 @@ void drt_renderer_destroy(drt_renderer *r) {
     if (r->accum) (void)hipFree(r->accum);
     if (r->rgba) (void)hipFree(r->rgba);
     if (r->counters) (void)hipFree(r->counters);
+    if (r->tile_counter) (void)hipFree(r->tile_counter);
+    if (r->samples) (void)hipFree(r->samples);
     if (r->ev_start) (void)hipEventDestroy(r->ev_start);
     if (r->ev_stop) (void)hipEventDestroy(r->ev_stop);
     delete r;
@@ -388,6 +410,7 @@ static int upload_scene(drt_renderer *r, const drt_scene *scene) {
     std::memcpy(v.root_min, ps.root_min, 12);
     std::memcpy(v.root_max, ps.root_max, 12);
     r->bvh_depth = ps.depth;
+    r->scene_has_alpha = ps.any_alpha_texture;
     r->uploaded_scene = scene;
     r->uploaded_revision = scene->host.revision;
     return DRT_OK;
@@ -431,6 +454,7 @@ static void fill_frame_params(const drt_renderer *r, const drt_camera *cam, Fram
     fp.stripe_rows = r->stripe_rows; fp.rank = r->rank; fp.world = r->world; fp.local_rows = r->local_rows;
     fp.accum = r->cur_accum(); fp.rgba = r->cur_rgba();
     fp.counters = r->counting ? r->counters : nullptr;
+    fp.vote_node = r->vote_node; fp.vote_shade = r->vote_shade; fp.vote_dir = r->vote_dir;
 }
 
 int drt_renderer_render_batch(drt_renderer *r, const drt_camera *cam, const drt_scene *scene, uint32_t n_frames,
@@ -456,7 +480,25 @@ int drt_renderer_render_batch(drt_renderer *r, const drt_camera *cam, const drt_
     if (r->counting) HIP_TRY(hipMemsetAsync(r->counters, 0, sizeof(drt_counters), r->stream));
 
     HIP_TRY(hipEventRecord(r->ev_start, r->stream));                   // Renderer.cu:97
-    HIP_TRY(launch_render(r->view, fp, r->bvh_depth, r->counting, r->stream, &r->kernel_name));
+    if (r->use_pixel_walk) {
+        HIP_TRY(launch_render(r->view, fp, r->bvh_depth, r->counting, r->stream, &r->kernel_name));
+    } else {
+        // split the batch so that the per-sample colour buffer of one launch stays within the budget
+        const size_t per_frame = (size_t)r->width * r->local_rows * 4 * sizeof(float);
+        uint32_t frames_per_launch = (uint32_t)std::max<size_t>(1, std::min<size_t>(n_frames, r->sample_budget / std::max<size_t>(per_frame, 1)));
+        const size_t need = per_frame * frames_per_launch;
+        if (need > r->samples_bytes) {
+            if (r->samples) { (void)hipFree(r->samples); r->samples = nullptr; r->samples_bytes = 0; }
+            HIP_TRY(hipMalloc(&r->samples, std::max<size_t>(need, 16)));
+            r->samples_bytes = need;
+        }
+        for (uint32_t done = 0; done < n_frames; done += frames_per_launch) {
+            fp.frame_first = r->frame_index + done;
+            fp.n_frames = std::min(frames_per_launch, n_frames - done);
+            HIP_TRY(launch_wave_queue(r->view, fp, r->bvh_depth, r->counting ? 2 : 0, r->scene_has_alpha, r->tile_counter,
+                                      r->samples, r->num_cus, r->stream, &r->kernel_name));
+        }
+    }
     HIP_TRY(hipEventRecord(r->ev_stop, r->stream));                    // Renderer.cu:105
     HIP_TRY(hipEventSynchronize(r->ev_stop));                          // blocking, Renderer.cu:106
     float ms = 0.f;

@@ -1,0 +1,480 @@
+// kernel_wave_queue.hip -- "wave_queue": persistent wave64 path tracer with lane refill and phase voting,
+// plus the ordered resolve kernel.
+//
+// Same arithmetic as pixel_walk (render_kernels.hip) and the same per-lane order of node visits and
+// triangle tests as the reference (BVH/BVHTraversal.cuh:14-134), so images are bit-identical; what changes
+// is how the 64 lanes of a wave are kept busy:
+//
+//   * PERSISTENT WAVES + SAMPLE QUEUE.  The grid is sized to the chip, not to the image.  The unit of work is
+//     one SAMPLE (pixel x frame index = one RayGen call, RayGen.cuh:63).  A wave pulls chunks of 64 samples
+//     (one 8x8 pixel tile, one frame index) from a global atomic counter (one atomic per 64 samples) and deals
+//     them to its lanes one by one: a lane that finishes its path takes the next sample at once, so no lane
+//     idles because a neighbour's path is longer (paths are 1..depth+1 rays long, RayGen.cuh:88-162), and the
+//     end-of-launch tail is one sample per lane, not one pixel x all frames.
+//   * ORDERED RESOLVE.  Each sample's colour goes to a float4 slot [frame][pixel] in HBM; resolve_kernel then
+//     adds the frames of a pixel in frame order, ((a + c_f) + c_f+1) + ..., exactly the order of
+//     accumulation_buffer += fcolor over successive launches (RenderKernel.cu:29-30), and writes accum + RGBA.
+//   * PHASE VOTING.  A lane is in one of four states: T = has a leaf triangle to test, N = has a node on its
+//     stack, R = needs a try of the bounce-direction rejection sampler, S = needs shading / a new sample.
+//     The wave loop ballots the states and runs ONE phase for all lanes in that state; T (one Moller-Trumbore
+//     test per lane, the dominant work) keeps running until enough lanes wait for another phase.
+//   * LDS.  Traversal stack (node reference + entry distance, 8 B) per lane in LDS, entry [level][tid]:
+//     conflict-free for ds_read/write_b64.  For scenes whose traversal data (child-box-pair records, leaf
+//     ranges, TriHot records) fits kLdsSceneBytes, every workgroup stages it in LDS once and all node /
+//     triangle fetches are 32-bit-addressed LDS gathers.
+// No MFMA (branchy scalar fp32 / u32).  Citations are relative to /root/reference/DustRayTracer/src/.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "device_access.hpp"
+#include "device_math.hpp"
+#include "device_scene.hpp"
+#include "render_kernels.hpp"
+
+namespace drt {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// per-lane path stage: what the S phase has to do next for this lane (kNeedDir lanes are served by R)
+enum : int { kNeedSample = 0, kTraceDone = 2, kShadowDone = 3, kFinished = 4, kPathDone = 5, kNeedDir = 6 };
+
+struct StackEntry { uint32_t ref; float dist; };
+
+DRT_DEV unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+DRT_DEV int lane_rank(unsigned long long mask) {        // set bits below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// MODE 0: lean (NORMALMODE, tonemap+gamma on, no sunlight, no RGBA texture, no counters); 1: every setting honoured
+// at run time; 2: = 1 + exact work counters
+template <int STACK, int MODE, bool LDS_SCENE>
+__global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc, const FrameParams fp,
+                                                              unsigned int *chunk_counter, uint32_t n_chunks, uint32_t tiles_x,
+                                                              float4 *samples) {
+    constexpr bool GENERAL = MODE >= 1;
+    constexpr bool COUNT = MODE == 2;
+    extern __shared__ uint4 lds_raw[];
+    StackEntry(*stack)[kThreads] = reinterpret_cast<StackEntry(*)[kThreads]>(lds_raw);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+
+    // ---- scene source: LDS copy (indexed in uint4 units from lds_raw) or HBM ----
+    constexpr uint32_t kSceneBase = (uint32_t)STACK * kThreads * sizeof(StackEntry) / 16;
+    const uint32_t hot_base = kSceneBase + sc.n_inner * 4u;
+    const uint32_t leaf_base = hot_base + sc.n_tris * 3u;
+    if (LDS_SCENE) {
+        const uint4 *g_inner = reinterpret_cast<const uint4 *>(sc.inner);
+        const uint4 *g_hot = reinterpret_cast<const uint4 *>(sc.tri_hot);
+        for (uint32_t i = tid; i < sc.n_inner * 4u; i += kThreads) lds_raw[kSceneBase + i] = g_inner[i];
+        for (uint32_t i = tid; i < sc.n_tris * 3u; i += kThreads) lds_raw[hot_base + i] = g_hot[i];
+        LeafRange *l_leaves = reinterpret_cast<LeafRange *>(lds_raw + leaf_base);
+        for (uint32_t i = tid; i < sc.n_leaves; i += kThreads) l_leaves[i] = sc.leaves[i];
+        __syncthreads();
+    }
+    auto fetch_tri = [&](int i) -> TriTest {
+        uint4 a, b; uint32_t c;
+        if (LDS_SCENE) {
+            const uint32_t q = hot_base + (uint32_t)i * 3u;
+            a = lds_raw[q]; b = lds_raw[q + 1]; c = lds_raw[q + 2].x;
+        } else {
+            const uint4 *q = reinterpret_cast<const uint4 *>(sc.tri_hot + i);
+            a = q[0]; b = q[1]; c = q[2].x;
+        }
+        TriTest t;
+        t.v0 = mk3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+        t.e1 = mk3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
+        t.e2 = mk3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c));
+        return t;
+    };
+    auto fetch_children = [&](uint32_t index) -> ChildPair {
+        uint4 a, b, c; uint2 r;
+        if (LDS_SCENE) {
+            const uint32_t q = kSceneBase + index * 4u;
+            a = lds_raw[q]; b = lds_raw[q + 1]; c = lds_raw[q + 2];
+            const uint4 d = lds_raw[q + 3]; r.x = d.x; r.y = d.y;
+        } else {
+            const uint4 *q = reinterpret_cast<const uint4 *>(sc.inner + index);
+            a = q[0]; b = q[1]; c = q[2];
+            r = *reinterpret_cast<const uint2 *>(&q[3]);
+        }
+        ChildPair p;
+        p.min1 = mk3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+        p.max1 = mk3(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y));
+        p.min2 = mk3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x));
+        p.max2 = mk3(__uint_as_float(c.y), __uint_as_float(c.z), __uint_as_float(c.w));
+        p.ref1 = r.x; p.ref2 = r.y;
+        return p;
+    };
+    auto fetch_leaf = [&](uint32_t id) -> LeafRange {
+        if (LDS_SCENE) return reinterpret_cast<const LeafRange *>(lds_raw + leaf_base)[id];
+        return sc.leaves[id];
+    };
+
+    const int vote_node = fp.vote_node, vote_shade = fp.vote_shade, vote_dir = fp.vote_dir;
+    const bool debug = GENERAL && fp.render_mode == 1;
+    const bool sun = GENERAL && fp.enable_sunlight && !debug;
+    const f3 root_min = ld3(sc.root_min), root_max = ld3(sc.root_max);
+    const uint32_t local_pixels = fp.width * fp.local_rows;
+
+    // ---- lane state ----
+    int stage = kNeedSample;
+    int sp = 0;                      // stack height
+    int cur = 0, end = 0;            // leaf cursor: triangles [cur, end) still to test
+    bool shadow = false;             // current traversal is RayTest (BVHTraversal.cuh:76-134)
+    bool occluded = false;
+    Ray ray = make_ray(mk3(0, 0, 0), mk3(0, 0, 1));
+    float hit_t = FLT_MAX, hit_u = 0, hit_v = 0;
+    int hit_prim = -1;
+    float heat = 0;
+    f3 light = mk3(0, 0, 0), throughput = mk3(1, 1, 1);
+    f3 bounce_origin = mk3(0, 0, 0), bounce_normal = mk3(0, 0, 0);      // kept across a shadow traversal / R tries
+    f2 tex_uv; tex_uv.x = 0; tex_uv.y = 1;
+    uint32_t seed = 0, slot = 0;     // slot: where this sample's colour goes in `samples`
+    int bounce = 0;
+    // wave-uniform sample pool: chunk = (tile, frame), pool_next = next unassigned sample of the chunk
+    uint32_t chunk = 0, pool_next = 64;
+    bool exhausted = false;
+    unsigned long long c_samples = 0, c_rays = 0, c_nodes = 0, c_inner = 0, c_tris = 0, c_htex = 0, c_hflat = 0,
+                       c_srays = 0, c_sinner = 0, c_stris = 0;
+    unsigned long long d_exec[4] = { 0, 0, 0, 0 }, d_lanes[4] = { 0, 0, 0, 0 };     // phase runs / lanes served
+
+    auto begin_closest = [&]() {                         // TraceRay.cu:15-20 + BVHTraversal.cuh:22-26
+        hit_t = FLT_MAX; hit_prim = -1; heat = 0; shadow = false;
+        cur = end = 0; sp = 0;
+        if (COUNT) c_rays++;
+        if (sc.root_ref != kNoNode) {
+            StackEntry e; e.ref = sc.root_ref; e.dist = slab_intersect(root_min, root_max, ray);
+            stack[0][tid] = e;
+            sp = 1;
+        }
+    };
+
+    // Wave loop.  One trip = maybe S, then R steps, then N steps, then T steps; every inner loop stops as soon as
+    // its own supply of lanes is low and another phase has enough lanes waiting (thresholds vote_*).
+    for (;;) {
+        // class masks (scalar): a lane is T if it has triangles, else N if it has stack entries, else R / S by stage
+        unsigned long long m_t = ballot(cur < end), m_sp = ballot(sp > 0);
+        unsigned long long m_dir = ballot(stage == kNeedDir), m_fin = ballot(stage == kFinished);
+        unsigned long long m_n = ~m_t & m_sp, m_idle = ~m_t & ~m_sp;
+        unsigned long long m_r = m_idle & m_dir, m_s = m_idle & ~m_dir & ~m_fin;
+        if ((m_t | m_n | m_r | m_s) == 0) break;
+
+        // ================= S: shade, finish paths, deal samples, generate primary rays =================
+        const int n_s = __popcll(m_s);
+        if (n_s >= vote_shade || (m_t == 0 && m_n == 0 && n_s > 0 && n_s >= __popcll(m_r))) {
+            if (COUNT) { d_exec[2]++; d_lanes[2] += (unsigned long long)n_s; }
+            const bool in_s = (m_s >> lane) & 1ull;
+            // (a) a closest-hit traversal finished: RayGen.cuh:90-134
+            if (in_s && stage == kTraceDone) {
+                seed += (uint32_t)bounce;                                                  // :91
+                bool path_done = false;
+                if (hit_prim < 0) {                                                        // :99-108
+                    if (debug && fp.debug_mode == 4) light = mk3(heat, heat, heat);
+                    else light = light + sky_model(ray.dir, ld3(fp.sky_color)) * throughput * fp.sky_intensity;
+                    path_done = true;
+                } else {
+                    const f3 uvw = mk3(1.0f - hit_u - hit_v, hit_u, hit_v);                // Intersection.cu:31
+                    const f3 position = ray.orig + ray.dir * hit_t;                        // ClosestHit.cuh:13
+                    const f3 face_n = ld3(sc.tri_hot[hit_prim].fn);
+                    const f3 normal = (dot(face_n, normalize(ray.dir)) > 0.f) ? (-1.f * face_n) : face_n;
+                    const TriCold cold = sc.tri_cold[hit_prim];                            // :111-118
+                    const MatDev mat = sc.mats[cold.material];
+                    if (mat.tex < 0) {
+                        throughput = throughput * ld3(mat.albedo);
+                        if (COUNT) c_hflat++;
+                    } else {
+                        tex_uv = interp_uv(cold, uvw);
+                        throughput = throughput * tex_get_pixel(sc, sc.texs[mat.tex], tex_uv);
+                        if (COUNT) c_htex++;
+                    }
+                    bounce_origin = position + (normal * 0.001f);                          // :121
+                    bounce_normal = normal;
+                    stage = kShadowDone;                                                   // (b) below, now or after the shadow ray
+                    occluded = true;
+                    if (sun) {                                                             // :124-128
+                        ray = make_ray(bounce_origin, ld3(fp.sunpos) + random_unit_vec3(seed) * 1.5f);
+                        if (COUNT) c_srays++;
+                        shadow = true; occluded = false; cur = end = 0; sp = 0;
+                        if (sc.root_ref != kNoNode && !(slab_intersect(root_min, root_max, ray) < 0)) {   // BVHTraversal.cuh:95-103
+                            StackEntry e; e.ref = sc.root_ref; e.dist = 0;
+                            stack[0][tid] = e;
+                            sp = 1;
+                        }
+                    }
+                    if (debug) {                                                           // :137-161 (the bounce draw before it has no visible effect)
+                        switch (fp.debug_mode) {
+                        case 0: light = throughput; break;
+                        case 1: light = normal; break;
+                        case 2: light = uvw; break;
+                        case 3: light = mk3(tex_uv.x, tex_uv.y, 0); break;
+                        case 4: light = mk3(0, 0.1f, 0.1f) + mk3(heat, heat, heat); break;
+                        default: break;
+                        }
+                        path_done = true;
+                    }
+                }
+                if (path_done) { stage = kPathDone; sp = 0; cur = end = 0; }
+            }
+            // (b) the sun shadow traversal (if any) is over: add sunlight, ask for a bounce direction  RayGen.cuh:126-134
+            if (in_s && stage == kShadowDone && sp == 0) {
+                if (sun && !occluded) light = light + ld3(fp.suncol) * throughput;
+                ++bounce;
+                // :88 loop condition.  The bounce direction (randomUnitSphereVec3's rejection loop) is drawn one
+                // candidate per R step; after the last bounce the reference still draws one, which nothing reads.
+                stage = (bounce <= fp.bounce_limit) ? kNeedDir : kPathDone;
+            }
+            // (c) path finished: post-process and park the sample's colour  RayGen.cuh:165-171
+            if (in_s && stage == kPathDone) {
+                if (!debug || fp.debug_mode == 0) {
+                    if (!GENERAL || fp.tone_mapping) light = uncharted2_filmic(light, fp.exposure);
+                    if (!GENERAL || fp.gamma_correction) light = gamma_correction(light);
+                }
+                samples[slot] = make_float4(light.x, light.y, light.z, 0.0f);
+                stage = kNeedSample;
+            }
+            // (d) deal the samples of the wave's chunk; pull a new chunk from the queue when it is used up
+            uint32_t my_k = 0, my_chunk = 0;
+            bool got = false;
+            {
+                bool need = in_s && stage == kNeedSample;
+                for (;;) {
+                    const unsigned long long m = ballot(need);
+                    if (m == 0) break;
+                    if (pool_next >= 64) {
+                        unsigned int c = 0;
+                        if (!exhausted && lane == 0) c = atomicAdd(chunk_counter, 1u);
+                        c = __builtin_amdgcn_readfirstlane(c);
+                        if (exhausted || c >= n_chunks) {
+                            exhausted = true;
+                            if (need) { stage = kFinished; need = false; }
+                            break;
+                        }
+                        chunk = c; pool_next = 0;
+                    }
+                    const int rank = lane_rank(m);
+                    const int avail = 64 - (int)pool_next;
+                    if (need && rank < avail) { my_k = pool_next + (uint32_t)rank; my_chunk = chunk; got = true; need = false; }
+                    pool_next += (uint32_t)min(__popcll(m), avail);
+                }
+            }
+            // (e) primary ray of the new sample  RayGen.cuh:63-86
+            if (got) {
+                const uint32_t tile = my_chunk / fp.n_frames, f_rel = my_chunk - tile * fp.n_frames;
+                const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+                const uint32_t x = tx * 8u + (my_k & 7u), ly = ty * 8u + (my_k >> 3);
+                if (x < fp.width && ly < fp.local_rows) {
+                    const uint32_t y = ((ly / fp.stripe_rows) * fp.world + fp.rank) * fp.stripe_rows + (ly % fp.stripe_rows);
+                    slot = f_rel * local_pixels + ly * fp.width + x;
+                    f2 screen_uv;
+                    screen_uv.x = ((float)x / (float)fp.width) * 2 - 1;
+                    screen_uv.y = ((float)y / (float)fp.height) * 2 - 1;
+                    seed = x + y * fp.width;
+                    seed *= fp.frame_first + f_rel;
+                    ray = camera_get_ray(fp, screen_uv, seed);
+                    light = mk3(0, 0, 0); throughput = mk3(1, 1, 1);
+                    tex_uv.x = 0; tex_uv.y = 1;
+                    bounce = 0;
+                    if (COUNT) c_samples++;
+                    begin_closest();
+                    stage = kTraceDone;
+                }
+                // a sample outside the image (partial tile) leaves the lane in kNeedSample: it asks again next time
+            }
+            m_sp = ballot(sp > 0);
+            m_dir = ballot(stage == kNeedDir); m_fin = ballot(stage == kFinished);
+        }
+
+        // ================= R: one candidate of the bounce direction per waiting lane (Random.cu:50-58, RayGen.cuh:133-134) ====
+        for (;;) {
+            m_r = ~m_t & ~m_sp & m_dir;
+            const int n_r = __popcll(m_r);
+            if (n_r == 0) break;
+            if (n_r < vote_dir && (m_t | (~m_t & m_sp)) != 0) break;
+            if (COUNT) { d_exec[3]++; d_lanes[3] += (unsigned long long)n_r; }
+            if ((m_r >> lane) & 1ull) {
+                f3 p;
+                if (random_unit_sphere_try(seed, p)) {
+                    ray = make_ray(bounce_origin, bounce_normal + p);
+                    begin_closest();
+                    stage = kTraceDone;
+                }
+            }
+            m_sp = ballot(sp > 0);
+            m_dir = ballot(stage == kNeedDir);
+        }
+
+        // ================= N: pop one stack entry per waiting lane (BVHTraversal.cuh:33-72 / :91-131) =================
+        for (;;) {
+            m_n = ~m_t & m_sp;
+            const int n_n = __popcll(m_n);
+            if (n_n == 0) break;
+            if (n_n < vote_node && m_t != 0) break;
+            if (COUNT) { d_exec[1]++; d_lanes[1] += (unsigned long long)n_n; }
+            if ((m_n >> lane) & 1ull) {
+                --sp;
+                const StackEntry e = stack[sp][tid];
+                bool visit = true;
+                if (!(GENERAL && shadow)) {
+                    if (!(-1.0f < e.dist && e.dist < FLT_MAX)) visit = false;                   // :38
+                    else if (hit_prim >= 0 && hit_t < e.dist) visit = false;                    // :41
+                }
+                if (visit) {
+                    if (GENERAL && !shadow) { heat += 0.05f; if (COUNT) c_nodes++; }            // :43
+                    if (e.ref & kLeafBit) {
+                        const LeafRange leaf = fetch_leaf(e.ref & ~kLeafBit);
+                        cur = leaf.start; end = leaf.start + leaf.count;
+                    } else {
+                        const ChildPair c = fetch_children(e.ref);
+                        const float d1 = slab_intersect(c.min1, c.max1, ray);
+                        const float d2 = slab_intersect(c.min2, c.max2, ray);
+                        bool push1, push2;
+                        if (GENERAL && shadow) { push1 = d1 >= 0; push2 = d2 >= 0; if (COUNT) c_sinner++; }   // :122-129
+                        else { push1 = d1 >= 0 && d1 < hit_t; push2 = d2 >= 0 && d2 < hit_t; if (COUNT) c_inner++; }   // :63-70
+                        const bool first_is_1 = d1 > d2;          // farther child first; child 2 first on ties
+                        StackEntry e1; e1.ref = c.ref1; e1.dist = d1;
+                        StackEntry e2; e2.ref = c.ref2; e2.dist = d2;
+                        const StackEntry ea = first_is_1 ? e1 : e2, eb = first_is_1 ? e2 : e1;
+                        const bool pa = first_is_1 ? push1 : push2, pb = first_is_1 ? push2 : push1;
+                        if (pa) { stack[sp][tid] = ea; ++sp; }
+                        if (pb) { stack[sp][tid] = eb; ++sp; }
+                    }
+                }
+            }
+            m_t = ballot(cur < end); m_sp = ballot(sp > 0);
+        }
+
+        // ================= T: one triangle per lane (Intersection.cu:4-36, BVHTraversal.cuh:46-57 / :105-117) ==========
+        for (;;) {
+            if (m_t == 0) break;
+            const unsigned long long idle = ~m_t & ~m_sp;
+            if (__popcll(~m_t & m_sp) >= vote_node || __popcll(idle & m_dir) >= vote_dir ||
+                __popcll(idle & ~m_dir & ~m_fin) >= vote_shade) break;
+            if (COUNT) { d_exec[0]++; d_lanes[0] += (unsigned long long)__popcll(m_t); }
+            if ((m_t >> lane) & 1ull) {
+                const int i = cur++;
+                const TriTest tri = fetch_tri(i);
+                float t, u, v;
+                const bool h = tri_intersect_flat(ray, tri.v0, tri.e1, tri.e2, t, u, v);
+                if (GENERAL && shadow) {
+                    if (COUNT) c_stris++;
+                    if (h && any_hit(sc, i, mk3(1.0f - u - v, u, v))) { occluded = true; cur = end = 0; sp = 0; }
+                } else {
+                    if (COUNT) c_tris++;
+                    if (h && t < hit_t) {
+                        if (!GENERAL || any_hit(sc, i, mk3(1.0f - u - v, u, v))) { hit_t = t; hit_prim = i; hit_u = u; hit_v = v; }
+                    }
+                }
+            }
+            m_t = ballot(cur < end);
+            if (GENERAL) m_sp = ballot(sp > 0);
+        }
+    }
+
+    if (COUNT && fp.counters) {
+        atomicAdd(&fp.counters[0], c_samples); atomicAdd(&fp.counters[1], c_rays); atomicAdd(&fp.counters[2], c_nodes);
+        atomicAdd(&fp.counters[3], c_inner); atomicAdd(&fp.counters[4], c_tris); atomicAdd(&fp.counters[5], c_htex);
+        atomicAdd(&fp.counters[6], c_hflat); atomicAdd(&fp.counters[7], c_srays); atomicAdd(&fp.counters[8], c_sinner);
+        atomicAdd(&fp.counters[9], c_stris);
+        if (lane == 0)
+            for (int k = 0; k < 4; k++) { atomicAdd(&fp.counters[10 + k], d_exec[k]); atomicAdd(&fp.counters[14 + k], d_lanes[k]); }
+    }
+}
+
+// RenderKernel.cu:29-34 for a batch of frames: per pixel, add the frames' colours in frame order, store the running sum
+// and the resolved RGBA32F texel (sum / last frame index, alpha 1).
+__global__ __launch_bounds__(256) void resolve_kernel(const float4 *samples, float *accum, float4 *rgba, uint32_t local_pixels,
+                                                      uint32_t n_frames, uint32_t last_frame_index) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= local_pixels) return;
+    f3 acc = ld3(accum + 3 * (size_t)p);
+    for (uint32_t f = 0; f < n_frames; f++) {
+        const float4 c = samples[(size_t)f * local_pixels + p];
+        acc = acc + mk3(c.x, c.y, c.z);
+    }
+    accum[3 * (size_t)p + 0] = acc.x; accum[3 * (size_t)p + 1] = acc.y; accum[3 * (size_t)p + 2] = acc.z;
+    const f3 out = acc / (float)last_frame_index;
+    rgba[p] = make_float4(out.x, out.y, out.z, 1.0f);
+}
+
+template <int STACK, int MODE, bool LDS_SCENE>
+hipError_t launch_one(const SceneView &sc, const FrameParams &fp, unsigned int *chunk_counter, float4 *samples,
+                      size_t lds_bytes, int num_cus, hipStream_t stream) {
+    const uint32_t tiles_x = (fp.width + 7) / 8, tiles_y = (fp.local_rows + 7) / 8;
+    auto kernel = wave_queue_kernel<STACK, MODE, LDS_SCENE>;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    // persistent grid: as many workgroups as the chip keeps resident (registers and LDS decide), never more than
+    // there are chunks to hand out.  Workgroups are independent, so a mis-estimate only costs speed.
+    static int per_cu_cache = 0;      // one value per instantiation
+    static size_t per_cu_lds = ~(size_t)0;
+    if (per_cu_cache == 0 || per_cu_lds != lds_bytes) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kThreads, lds_bytes) != hipSuccess || n < 1) n = 1;
+        per_cu_cache = std::min(n, 8);
+        per_cu_lds = lds_bytes;
+    }
+    const uint64_t n_chunks = (uint64_t)tiles_x * tiles_y * fp.n_frames;
+    if (n_chunks > 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)num_cus * per_cu_cache, (n_chunks + 3) / 4));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), lds_bytes, stream, sc, fp, chunk_counter, (uint32_t)n_chunks, tiles_x, samples);
+    return hipGetLastError();
+}
+
+template <int STACK>
+hipError_t launch_stack(const SceneView &sc, const FrameParams &fp, int mode, bool lds_scene, unsigned int *chunk_counter,
+                        float4 *samples, size_t lds_bytes, int num_cus, hipStream_t stream) {
+    if (lds_scene) {
+        if (mode == 0) return launch_one<STACK, 0, true>(sc, fp, chunk_counter, samples, lds_bytes, num_cus, stream);
+        if (mode == 1) return launch_one<STACK, 1, true>(sc, fp, chunk_counter, samples, lds_bytes, num_cus, stream);
+        return launch_one<STACK, 2, true>(sc, fp, chunk_counter, samples, lds_bytes, num_cus, stream);
+    }
+    if (mode == 0) return launch_one<STACK, 0, false>(sc, fp, chunk_counter, samples, lds_bytes, num_cus, stream);
+    if (mode == 1) return launch_one<STACK, 1, false>(sc, fp, chunk_counter, samples, lds_bytes, num_cus, stream);
+    return launch_one<STACK, 2, false>(sc, fp, chunk_counter, samples, lds_bytes, num_cus, stream);
+}
+
+}  // namespace
+
+size_t wave_queue_scene_lds_bytes(const SceneView &sc) {
+    return (size_t)sc.n_inner * sizeof(InnerNode) + (size_t)sc.n_tris * sizeof(TriHot) + (((size_t)sc.n_leaves * sizeof(LeafRange) + 15) & ~(size_t)15);
+}
+
+size_t wave_queue_sample_bytes(const FrameParams &fp) {
+    return (size_t)fp.width * fp.local_rows * fp.n_frames * sizeof(float4);
+}
+
+hipError_t launch_wave_queue(const SceneView &sc, const FrameParams &fp, int bvh_depth, int mode, bool scene_has_alpha,
+                             unsigned int *chunk_counter, void *samples, int num_cus, hipStream_t stream, const char **kernel_name) {
+    if (fp.width == 0 || fp.local_rows == 0 || fp.n_frames == 0) return hipSuccess;
+    if (mode == 0 && (scene_has_alpha || fp.render_mode != 0 || fp.enable_sunlight || !fp.tone_mapping || !fp.gamma_correction)) mode = 1;
+    const int stack = bvh_depth <= 8 ? 8 : bvh_depth <= 16 ? 16 : bvh_depth <= 32 ? 32 : 64;
+    if (bvh_depth > 64) return hipErrorInvalidValue;
+    const size_t stack_bytes = (size_t)stack * kThreads * sizeof(StackEntry);
+    const size_t scene_bytes = wave_queue_scene_lds_bytes(sc);
+    const bool lds_scene = scene_bytes <= kLdsSceneBytes;
+    const size_t lds_bytes = stack_bytes + (lds_scene ? scene_bytes : 0);
+    hipError_t e = hipMemsetAsync(chunk_counter, 0, sizeof(unsigned int), stream);
+    if (e != hipSuccess) return e;
+    static const char *names[2][3] = { { "wave_queue<lean,hbm-scene>", "wave_queue<general,hbm-scene>", "wave_queue<counting,hbm-scene>" },
+                                       { "wave_queue<lean,lds-scene>", "wave_queue<general,lds-scene>", "wave_queue<counting,lds-scene>" } };
+    if (kernel_name) *kernel_name = names[lds_scene ? 1 : 0][mode];
+    float4 *s4 = static_cast<float4 *>(samples);
+    switch (stack) {
+    case 8: e = launch_stack<8>(sc, fp, mode, lds_scene, chunk_counter, s4, lds_bytes, num_cus, stream); break;
+    case 16: e = launch_stack<16>(sc, fp, mode, lds_scene, chunk_counter, s4, lds_bytes, num_cus, stream); break;
+    case 32: e = launch_stack<32>(sc, fp, mode, lds_scene, chunk_counter, s4, lds_bytes, num_cus, stream); break;
+    default: e = launch_stack<64>(sc, fp, mode, lds_scene, chunk_counter, s4, lds_bytes, num_cus, stream); break;
+    }
+    if (e != hipSuccess) return e;
+    const uint32_t local_pixels = fp.width * fp.local_rows;
+    hipLaunchKernelGGL(resolve_kernel, dim3((local_pixels + 255) / 256), dim3(256), 0, stream, s4, fp.accum,
+                       reinterpret_cast<float4 *>(fp.rgba), local_pixels, fp.n_frames, fp.frame_first + fp.n_frames - 1);
+    return hipGetLastError();
+}
+
+}  // namespace drt

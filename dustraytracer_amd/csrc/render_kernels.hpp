@@ -10,6 +10,15 @@ namespace drt {
 hipError_t launch_render(const SceneView &scene, const FrameParams &frame, int bvh_depth, bool count_work,
                          hipStream_t stream, const char **kernel_name);
 
+// wave_queue (kernel_wave_queue.hip): persistent waves + tile queue + phase voting.
+// mode 0 = lean (auto-upgraded to 1 when a setting or the scene needs it), 1 = general, 2 = general + work counters.
+constexpr size_t kLdsSceneBytes = 40 * 1024;     // stage the traversal data in LDS when it is at most this big
+// `samples` must hold wave_queue_sample_bytes(frame) bytes (one float4 per pixel and frame of the launch); the launch
+// runs the tracing kernel and then the ordered resolve kernel on `stream`.
+size_t wave_queue_sample_bytes(const FrameParams &frame);
+hipError_t launch_wave_queue(const SceneView &scene, const FrameParams &frame, int bvh_depth, int mode, bool scene_has_alpha,
+                             unsigned int *chunk_counter, void *samples, int num_cus, hipStream_t stream, const char **kernel_name);
+
 hipError_t launch_assemble(const void *gathered, void *image, uint32_t width, uint32_t height, uint32_t stripe_rows,
                            uint32_t world, uint32_t padded_rows, hipStream_t stream);
 

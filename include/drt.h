@@ -104,6 +104,8 @@ typedef struct drt_texture_info { int32_t width, height, components; } drt_textu
 typedef struct drt_counters {
     uint64_t samples, rays, node_visits, inner_visits, tri_tests, hits_textured, hits_flat,
              shadow_rays, inner_visits_shadow, tri_tests_shadow;
+    /* wave_queue kernel only: executions of the T / N / S / R phase (per wave) and lanes served by them */
+    uint64_t phase_execs[4], phase_lanes[4];
 } drt_counters;
 
 typedef struct drt_scene drt_scene;         /* replaces struct Scene, Core/Scene/Scene.cuh:41-57 */

@@ -38,6 +38,13 @@
 typedef struct { float x, y, z; } f3;
 typedef struct { float x, y; } f2;
 
+/* Optional per-lane step trace (single-threaded runs only; used by tools/sim_schedule.py to study
+ * wave scheduling policies): 'N' = stack pop, 'T' = triangle test, 'R' = one try of the rejection
+ * sampler, 'S' = end of ray (shade), 'P' = end of path, 'X' = end of pixel. */
+static unsigned char *g_trace = NULL;
+static size_t g_trace_len = 0, g_trace_cap = 0;
+static inline void trace(unsigned char c) { if (g_trace && g_trace_len < g_trace_cap) g_trace[g_trace_len++] = c; }
+
 /* ---- helper_math.cuh subset (each op rounds once; no contraction) ---- */
 static inline f3 v3(float x, float y, float z) { f3 r = { x, y, z }; return r; }
 static inline f3 add3(f3 a, f3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }          /* :351 */
@@ -91,6 +98,7 @@ static inline f3 random_unit_sphere_vec3(uint32_t *seed, uint64_t *iters)       
         f3 p = random_unit_vec3(seed);
         float len = length3(p);
         if (iters) ++*iters;
+        trace('R');
         if ((len * len) < 1)
             return p;
     }
@@ -238,6 +246,7 @@ static void traverse_bvh(const ray_t *ray, int root, hit_payload *closest, const
     while (sp > 0) {
         const o_bvh_node *node = &sc->nodes[idx_stack[--sp]];
         float node_dist = dist_stack[sp];
+        trace('N');
         if (!(interval_min < node_dist && node_dist < interval_max)) continue;           /* :38 */
         if (closest->prim != NULL && closest->t < node_dist) continue;                   /* :41 */
         closest->color = add3(closest->color, scale3(v3(1, 1, 1), 0.05f));               /* :43 */
@@ -247,6 +256,7 @@ static void traverse_bvh(const ray_t *ray, int root, hit_payload *closest, const
             for (int i = node->prim_start; i < node->prim_start + node->prim_count; i++) {
                 const o_triangle *tri = &sc->tris[i];
                 short_hit h = tri_intersect(ray, tri->p);
+                trace('T');
                 if (cnt) cnt->tri_tests++;
                 if (h.hit && h.t < closest->t) {                                         /* :51 */
                     if (!any_hit(sc, tri, h.uvw, cnt)) continue;
@@ -457,6 +467,7 @@ static f3 ray_gen(uint32_t x, uint32_t y, uint32_t max_x, uint32_t max_y, const 
     for (int i = 0; i <= bounces; i++) {                                                    /* :88 */
         hit_payload payload = trace_ray(&ray, sc, cnt);
         seed += (uint32_t)i;                                                                /* :91 */
+        trace('S');
 
         if (payload.prim == NULL) {                                                         /* :99-108 */
             if (set->debug_mode == 4 && debug) {
@@ -503,6 +514,7 @@ static f3 ray_gen(uint32_t x, uint32_t y, uint32_t max_x, uint32_t max_y, const 
         }
     }
 
+    trace('P');
     if (!debug || set->debug_mode == 0) {                                                   /* :165-169 */
         if (set->tone_mapping) light = uncharted2_filmic(light, cf->exposure);
         if (set->gamma_correction) light = gamma_correction(light);
@@ -539,6 +551,7 @@ static void *worker(void *arg)
                                &j->cf, &j->sf, f, j->scene, j->set, cnt);
                 acc = add3(acc, c);                                                         /* :29 */
             }
+            trace('X');
             st3(&j->accum[3 * p], acc);
             f3 out = divs3(acc, (float)(f - 1));                                            /* :30 */
             j->rgba[4 * p + 0] = out.x; j->rgba[4 * p + 1] = out.y;
@@ -590,6 +603,23 @@ void o_render(const o_scene *scene, const o_camera *cam, const o_settings *set,
     if (counters)
         for (int t = 0; t < n_threads; t++) add_counters(counters, &jobs[t].counters);
     free(jobs); free(th);
+}
+
+/* Single-threaded render of a pixel rectangle that records the step trace (see g_trace). Returns bytes written. */
+size_t o_trace_steps(const o_scene *scene, const o_camera *cam, const o_settings *set, int32_t W, int32_t H,
+                     int32_t x0, int32_t y0, int32_t x1, int32_t y1, uint32_t n_frames, unsigned char *buf, size_t cap)
+{
+    cam_frame cf = camera_frame(cam, (float)(uint32_t)W, (float)(uint32_t)H);
+    sun_frame sf = sun_frame_of(set);
+    g_trace = buf; g_trace_len = 0; g_trace_cap = cap;
+    for (int32_t y = y0; y < y1; y++)
+        for (int32_t x = x0; x < x1; x++) {
+            for (uint32_t f = 1; f <= n_frames; f++)
+                (void)ray_gen((uint32_t)x, (uint32_t)y, (uint32_t)W, (uint32_t)H, &cf, &sf, f, scene, set, NULL);
+            trace('X');
+        }
+    g_trace = NULL;
+    return g_trace_len;
 }
 
 void o_default_settings(o_settings *s)                               /* Scene/RendererSettings.h:22-34 */

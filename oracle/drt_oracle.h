@@ -19,6 +19,7 @@
 #ifndef DRT_ORACLE_H
 #define DRT_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -135,6 +136,11 @@ void o_render(const o_scene *scene, const o_camera *cam, const o_settings *set,
               float *accum, float *rgba, int32_t n_threads,
               int32_t stripe_rows, int32_t rank, int32_t world,
               o_counters *counters);
+
+/* Step trace of a pixel rectangle (single-threaded): bytes 'N' pop, 'T' triangle test, 'R' sampler try,
+ * 'S' ray shaded, 'P' path done, 'X' pixel done.  For tools/sim_schedule.py. */
+size_t o_trace_steps(const o_scene *scene, const o_camera *cam, const o_settings *set, int32_t W, int32_t H,
+                     int32_t x0, int32_t y0, int32_t x1, int32_t y1, uint32_t n_frames, unsigned char *buf, size_t cap);
 
 /* ---- known-answer-test entry points for the leaf functions ---- */
 uint32_t o_pcg_hash(uint32_t v);                                   /* Random.cu:6-11 */

@@ -124,3 +124,20 @@ def test_live_reference_binary_when_present(kat_golden):
     v, s, _ = oracle.kat_unitsphere(seeds)
     rv, rs = rk.unitsphere(seeds)
     assert np.array_equal(bits(v), bits(rv)) and np.array_equal(s, rs)
+
+
+def test_sphere_accept_shortcut():
+    """The HIP kernels test  dot(p,p) < 1  instead of  len*len < 1, len = sqrtf(dot(p,p))  (Random.cu:54-55).
+    Equivalence for every float the dot product can take: all of [0.5, 2) exhaustively (the candidates are
+    normalised, so dot(p,p) is within a few ulp of 1), plus a random sample of the rest and the specials."""
+    one = np.float32(1)
+    lo, hi = np.float32(0.5).view(np.uint32), np.float32(2.0).view(np.uint32)
+    d = np.arange(lo, hi, dtype=np.uint32).view(np.float32)
+    length = np.sqrt(d)
+    assert np.array_equal((length * length) < one, d < one)
+    rng = np.random.default_rng(3)
+    d = rng.integers(0, 0x7F800001, 2_000_000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    d = np.concatenate([d, np.array([0.0, np.inf, np.nan, 1.0, np.nextafter(np.float32(1), np.float32(0))], np.float32)])
+    with np.errstate(invalid="ignore", over="ignore"):
+        length = np.sqrt(d)
+        assert np.array_equal((length * length) < one, d < one)

@@ -1,0 +1,7 @@
+"""GPU box: sweep the wave_queue voting thresholds on a workload (each setting in a fresh process)."""
+import os, subprocess, sys
+combos = [(12, 36, 8), (12, 36, 4), (12, 28, 8), (16, 16, 16), (12, 24, 12), (8, 36, 8), (16, 36, 8), (12, 44, 8), (12, 36, 16), (20, 36, 12), (12, 52, 8), (24, 48, 16)]
+for n, s, r in combos:
+    env = dict(os.environ, DRT_VOTE_N=str(n), DRT_VOTE_S=str(s), DRT_VOTE_R=str(r))
+    out = subprocess.run([sys.executable, "tools/phase_stats.py"] + sys.argv[1:], env=env, capture_output=True, text=True).stdout.strip().splitlines()
+    print("N %2d S %2d R %2d | %s | %s" % (n, s, r, out[-1].split("ms")[-1].strip() if out else "?", out[-2] if len(out) > 1 else ""), flush=True)
