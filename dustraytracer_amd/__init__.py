@@ -211,6 +211,7 @@ _sig("drt_renderer_get_counters", C.c_int, _P, C.POINTER(Counters))
 _sig("drt_renderer_kernel_info", C.c_int, _P, C.c_char_p, C.c_size_t)
 _sig("drt_assemble_shards", C.c_int, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P)
 _sig("drt_shard_rows", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
+_sig("drt_debug_check_rcp", C.c_int, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 
 EXPORTED_SYMBOLS = [n for n in dir(_lib) if n.startswith("drt_")]
 
@@ -405,6 +406,13 @@ class Renderer:
         buf = C.create_string_buffer(128)
         _check(_lib.drt_renderer_kernel_info(self._h, buf, 128))
         return buf.value.decode()
+
+
+def debug_check_rcp(device=0):
+    """(mismatches, fast-path count) of the kernels' exact_rcp vs IEEE 1.0f/x over all 2^32 floats."""
+    bad, fast = C.c_uint64(0), C.c_uint64(0)
+    _check(_lib.drt_debug_check_rcp(device, C.byref(bad), C.byref(fast)))
+    return int(bad.value), int(fast.value)
 
 
 def assemble_shards(gathered_ptr, image_ptr, width, height, stripe_rows, world, padded_rows, stream_ptr=None):

@@ -119,6 +119,25 @@ DRT_DEV bool tri_intersect(const Ray &ray, f3 v0, f3 e1, f3 e2, float &t_out, f3
     return false;
 }
 
+// 1.0f / x, correctly rounded, for the triangle test.  Same refinement chain as the compiler's IEEE division
+// expansion (v_rcp_f32, one Newton step on the reciprocal, two FMA corrections of the quotient) without the
+// v_div_scale / v_div_fmas / v_div_fixup wrapping that only matters when 1/x under- or overflows.  The triangle
+// test uses the result only when |det| >= 1e-6, where it is bit-identical to 1.0f / x: checked for EVERY float
+// with 2^-100 <= |x| <= 2^100 by tests/test_gpu_parity.py::test_exact_rcp_exhaustive (drt_debug_check_rcp);
+// outside that range (and for 0, inf, NaN) the function falls back to the plain division.
+DRT_DEV float exact_rcp(float x) {
+    const float ax = __builtin_fabsf(x);
+    if (!(ax >= 0x1p-100f && ax <= 0x1p100f)) return 1.0f / x;
+    float r = __builtin_amdgcn_rcpf(x);
+    float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = r;                                   // 1 * r
+    float rem = __builtin_fmaf(-x, q, 1.0f);
+    q = __builtin_fmaf(rem, r, q);
+    rem = __builtin_fmaf(-x, q, 1.0f);
+    return __builtin_fmaf(rem, r, q);
+}
+
 // Same test, straight-line: every quantity is computed, the four rejections are combined at the end.
 // A rejected lane may have divided by a tiny or zero det; its u, v, t are then garbage and never used.
 // NaN behaves as in the branchy form: comparisons with NaN are false, so only `t > eps` rejects it.
@@ -126,7 +145,7 @@ DRT_DEV bool tri_intersect_flat(const Ray &ray, f3 v0, f3 e1, f3 e2, float &t, f
     f3 pvec = cross(ray.dir, e2);
     float det = dot(e1, pvec);
     bool ok = !((det > -DRT_TRIANGLE_EPSILON) & (det < DRT_TRIANGLE_EPSILON));
-    float inv_det = 1.0f / det;
+    float inv_det = exact_rcp(det);
     f3 tvec = ray.orig - v0;
     u = inv_det * dot(tvec, pvec);
     ok = ok & !((u < 0.0f) | (u > 1.0f));

@@ -530,6 +530,21 @@ int drt_renderer_read_accum(drt_renderer *r, float *dst, size_t dst_floats) {
     return read_back(r, r ? r->cur_accum() : nullptr, 3, dst, dst_floats);
 }
 
+int drt_debug_check_rcp(int32_t device, uint64_t *mismatches, uint64_t *fast_path_count) {
+    if (!mismatches || !fast_path_count) return fail(DRT_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, 2 * sizeof(unsigned long long)));
+    hipError_t e = hipMemset(d, 0, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = launch_check_rcp(0u, 1ull << 32, d, nullptr);
+    unsigned long long h[2] = { 0, 0 };
+    if (e == hipSuccess) e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(DRT_ERR_DEVICE, hipGetErrorString(e));
+    *mismatches = h[0]; *fast_path_count = h[1];
+    return DRT_OK;
+}
+
 int drt_assemble_shards(const void *gathered, void *image, uint32_t width, uint32_t height, uint32_t stripe_rows,
                         uint32_t world, uint32_t padded_rows, void *hip_stream) {
     if (!gathered || !image || stripe_rows == 0 || world == 0) return fail(DRT_ERR_INVALID, "bad argument");

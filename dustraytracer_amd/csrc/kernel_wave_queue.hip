@@ -44,6 +44,26 @@ enum : int { kNeedSample = 0, kTraceDone = 2, kShadowDone = 3, kFinished = 4, kP
 struct StackEntry { uint32_t ref; float dist; };
 
 DRT_DEV unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// LDS reads through 32-bit address-space-3 pointers (byte offset within the workgroup's LDS allocation): keeps the
+// address arithmetic in 32 bits (v_mad_u32_u24) instead of a 64-bit flat pointer computation.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+#if defined(__HIP_DEVICE_COMPILE__)
+DRT_DEV uint4 lds_load4(uint32_t byte_off) {
+    const u32x4_t v = *(__attribute__((address_space(3))) const u32x4_t *)byte_off;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+DRT_DEV uint2 lds_load2(uint32_t byte_off) {
+    const u32x2_t v = *(__attribute__((address_space(3))) const u32x2_t *)byte_off;
+    return make_uint2(v.x, v.y);
+}
+DRT_DEV uint32_t lds_load1(uint32_t byte_off) { return *(__attribute__((address_space(3))) const uint32_t *)byte_off; }
+#else       // host pass: declarations only (never called on the host)
+uint4 lds_load4(uint32_t byte_off);
+uint2 lds_load2(uint32_t byte_off);
+uint32_t lds_load1(uint32_t byte_off);
+#endif
 DRT_DEV int lane_rank(unsigned long long mask) {        // set bits below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
@@ -74,11 +94,13 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
         for (uint32_t i = tid; i < sc.n_leaves; i += kThreads) l_leaves[i] = sc.leaves[i];
         __syncthreads();
     }
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds_raw);     // low 32 bits of the flat address = LDS offset
+    const uint32_t lds_inner = lds_base + kSceneBase * 16u, lds_hot = lds_base + hot_base * 16u, lds_leaf = lds_base + leaf_base * 16u;
     auto fetch_tri = [&](int i) -> TriTest {
         uint4 a, b; uint32_t c;
         if (LDS_SCENE) {
-            const uint32_t q = hot_base + (uint32_t)i * 3u;
-            a = lds_raw[q]; b = lds_raw[q + 1]; c = lds_raw[q + 2].x;
+            const uint32_t q = lds_hot + __umul24((uint32_t)i, 48u);
+            a = lds_load4(q); b = lds_load4(q + 16); c = lds_load1(q + 32);
         } else {
             const uint4 *q = reinterpret_cast<const uint4 *>(sc.tri_hot + i);
             a = q[0]; b = q[1]; c = q[2].x;
@@ -92,9 +114,8 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
     auto fetch_children = [&](uint32_t index) -> ChildPair {
         uint4 a, b, c; uint2 r;
         if (LDS_SCENE) {
-            const uint32_t q = kSceneBase + index * 4u;
-            a = lds_raw[q]; b = lds_raw[q + 1]; c = lds_raw[q + 2];
-            const uint4 d = lds_raw[q + 3]; r.x = d.x; r.y = d.y;
+            const uint32_t q = lds_inner + index * 64u;
+            a = lds_load4(q); b = lds_load4(q + 16); c = lds_load4(q + 32); r = lds_load2(q + 48);
         } else {
             const uint4 *q = reinterpret_cast<const uint4 *>(sc.inner + index);
             a = q[0]; b = q[1]; c = q[2];
@@ -109,7 +130,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
         return p;
     };
     auto fetch_leaf = [&](uint32_t id) -> LeafRange {
-        if (LDS_SCENE) return reinterpret_cast<const LeafRange *>(lds_raw + leaf_base)[id];
+        if (LDS_SCENE) { const uint2 v = lds_load2(lds_leaf + id * 8u); LeafRange l; l.start = (int)v.x; l.count = (int)v.y; return l; }
         return sc.leaves[id];
     };
 
@@ -166,7 +187,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
         const int n_s = __popcll(m_s);
         if (n_s >= vote_shade || (m_t == 0 && m_n == 0 && n_s > 0 && n_s >= __popcll(m_r))) {
             if (COUNT) { d_exec[2]++; d_lanes[2] += (unsigned long long)n_s; }
-            const bool in_s = (m_s >> lane) & 1ull;
+            const bool in_s = !(cur < end) && !(sp > 0) && stage != kNeedDir && stage != kFinished;
             // (a) a closest-hit traversal finished: RayGen.cuh:90-134
             if (in_s && stage == kTraceDone) {
                 seed += (uint32_t)bounce;                                                  // :91
@@ -294,7 +315,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
             if (n_r == 0) break;
             if (n_r < vote_dir && (m_t | (~m_t & m_sp)) != 0) break;
             if (COUNT) { d_exec[3]++; d_lanes[3] += (unsigned long long)n_r; }
-            if ((m_r >> lane) & 1ull) {
+            if (!(cur < end) && !(sp > 0) && stage == kNeedDir) {
                 f3 p;
                 if (random_unit_sphere_try(seed, p)) {
                     ray = make_ray(bounce_origin, bounce_normal + p);
@@ -313,7 +334,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
             if (n_n == 0) break;
             if (n_n < vote_node && m_t != 0) break;
             if (COUNT) { d_exec[1]++; d_lanes[1] += (unsigned long long)n_n; }
-            if ((m_n >> lane) & 1ull) {
+            if (!(cur < end) && sp > 0) {
                 --sp;
                 const StackEntry e = stack[sp][tid];
                 bool visit = true;
@@ -353,7 +374,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
             if (__popcll(~m_t & m_sp) >= vote_node || __popcll(idle & m_dir) >= vote_dir ||
                 __popcll(idle & ~m_dir & ~m_fin) >= vote_shade) break;
             if (COUNT) { d_exec[0]++; d_lanes[0] += (unsigned long long)__popcll(m_t); }
-            if ((m_t >> lane) & 1ull) {
+            if (cur < end) {
                 const int i = cur++;
                 const TriTest tri = fetch_tri(i);
                 float t, u, v;
@@ -399,6 +420,23 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float4 *samples, flo
     rgba[p] = make_float4(out.x, out.y, out.z, 1.0f);
 }
 
+// Debug: compares exact_rcp(x) with 1.0f / x for every float bit pattern in [first, first + count).
+__global__ __launch_bounds__(256) void check_rcp_kernel(uint32_t first, unsigned long long count, unsigned long long *mismatches,
+                                                        unsigned long long *fast_path) {
+    unsigned long long bad = 0, fast = 0;
+    for (unsigned long long k = (unsigned long long)blockIdx.x * 256u + threadIdx.x; k < count; k += (unsigned long long)gridDim.x * 256u) {
+        const float x = __uint_as_float(first + (uint32_t)k);
+        const float a = exact_rcp(x), b = 1.0f / x;
+        const uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+        const bool both_nan = (a != a) && (b != b);
+        if (ua != ub && !both_nan) bad++;
+        const float ax = __builtin_fabsf(x);
+        if (ax >= 0x1p-100f && ax <= 0x1p100f) fast++;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+    if (fast) atomicAdd(fast_path, fast);
+}
+
 template <int STACK, int MODE, bool LDS_SCENE>
 hipError_t launch_one(const SceneView &sc, const FrameParams &fp, unsigned int *chunk_counter, float4 *samples,
                       size_t lds_bytes, int num_cus, hipStream_t stream) {
@@ -439,6 +477,11 @@ hipError_t launch_stack(const SceneView &sc, const FrameParams &fp, int mode, bo
 }
 
 }  // namespace
+
+hipError_t launch_check_rcp(uint32_t first_bits, unsigned long long count, unsigned long long *d_out2, hipStream_t stream) {
+    hipLaunchKernelGGL(check_rcp_kernel, dim3(4096), dim3(256), 0, stream, first_bits, count, d_out2, d_out2 + 1);
+    return hipGetLastError();
+}
 
 size_t wave_queue_scene_lds_bytes(const SceneView &sc) {
     return (size_t)sc.n_inner * sizeof(InnerNode) + (size_t)sc.n_tris * sizeof(TriHot) + (((size_t)sc.n_leaves * sizeof(LeafRange) + 15) & ~(size_t)15);

@@ -19,6 +19,9 @@ size_t wave_queue_sample_bytes(const FrameParams &frame);
 hipError_t launch_wave_queue(const SceneView &scene, const FrameParams &frame, int bvh_depth, int mode, bool scene_has_alpha,
                              unsigned int *chunk_counter, void *samples, int num_cus, hipStream_t stream, const char **kernel_name);
 
+// debug: d_out2[0] += #floats in [first_bits, first_bits+count) where exact_rcp != 1.0f/x, d_out2[1] += #floats on its fast path
+hipError_t launch_check_rcp(uint32_t first_bits, unsigned long long count, unsigned long long *d_out2, hipStream_t stream);
+
 hipError_t launch_assemble(const void *gathered, void *image, uint32_t width, uint32_t height, uint32_t stripe_rows,
                            uint32_t world, uint32_t padded_rows, hipStream_t stream);
 

@@ -179,6 +179,8 @@ int           drt_renderer_kernel_info(const drt_renderer *r, char *buf, size_t 
  * `image` = full width*height float4.  Runs on `hip_stream`. */
 int           drt_assemble_shards(const void *gathered, void *image, uint32_t width, uint32_t height,
                                   uint32_t stripe_rows, uint32_t world, uint32_t padded_rows, void *hip_stream);
+/* Self-check of the kernels' reciprocal (device_math.hpp exact_rcp) against IEEE 1.0f/x over all 2^32 float bit patterns. */
+int           drt_debug_check_rcp(int32_t device, uint64_t *mismatches, uint64_t *fast_path_count);
 uint32_t      drt_shard_rows(uint32_t height, uint32_t stripe_rows, uint32_t rank, uint32_t world);
 
 #ifdef __cplusplus

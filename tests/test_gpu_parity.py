@@ -257,6 +257,14 @@ def test_external_buffers_and_stream():
     compare(rgba.cpu().numpy(), ref, "external buffers")
 
 
+def test_exact_rcp_exhaustive():
+    """device_math.hpp exact_rcp (used by the triangle test instead of the compiler's 1.0f/x expansion) must equal
+    IEEE division for EVERY float: all 2^32 bit patterns are compared on the device."""
+    bad, fast = drt.debug_check_rcp(0)
+    assert bad == 0
+    assert fast > 3_000_000_000          # the fast path really covers 2^-100 <= |x| <= 2^100 (2 * 200 * 2^23 patterns)
+
+
 def test_full_size_properties(renderer):
     """BASELINE config C2 at full size (1920x1080, 8 spp, depth 8): size-independent properties.
     The oracle would take ~1 min here, so the whole frame is checked through invariants and a
