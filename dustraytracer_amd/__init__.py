@@ -211,6 +211,8 @@ _sig("drt_renderer_get_counters", C.c_int, _P, C.POINTER(Counters))
 _sig("drt_renderer_kernel_info", C.c_int, _P, C.c_char_p, C.c_size_t)
 _sig("drt_assemble_shards", C.c_int, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P)
 _sig("drt_shard_rows", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
+_sig("drt_debug_kat", C.c_int, C.c_int32, C.c_int32, _P, C.c_size_t, _P, C.c_size_t, C.c_uint32, C.POINTER(_CameraPOD), C.c_uint32, C.c_uint32)
+_sig("drt_debug_hash_cycles", C.c_int, C.c_int32, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32))
 _sig("drt_debug_check_rcp", C.c_int, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 
 EXPORTED_SYMBOLS = [n for n in dir(_lib) if n.startswith("drt_")]
@@ -406,6 +408,28 @@ class Renderer:
         buf = C.create_string_buffer(128)
         _check(_lib.drt_renderer_kernel_info(self._h, buf, 128))
         return buf.value.decode()
+
+
+_KAT_WORDS = {0: (1, 5), 1: (1, 5), 2: (12, 1), 3: (15, 5), 4: (3, 7), 5: (1, 3)}
+
+
+def debug_kat(which, inputs, cam=None, width=0, height=0, device=0):
+    """Runs device leaf function `which` (see drt.h drt_debug_kat) on uint32-viewed inputs [n, words]; returns uint32 [n, words]."""
+    win, wout = _KAT_WORDS[which]
+    a = np.ascontiguousarray(inputs).view(np.uint32).reshape(-1, win)
+    out = np.zeros((len(a), wout), np.uint32)
+    pod = cam._pod() if cam is not None else None
+    _check(_lib.drt_debug_kat(device, which, a.ctypes.data, a.nbytes, out.ctypes.data, out.nbytes, len(a),
+                              C.byref(pod) if pod is not None else None, width, height))
+    return out
+
+
+def debug_hash_cycles(max_len=64, cap=4096, device=0):
+    """[(value, cycle length)] for every 32-bit value on a pcg_hash cycle of length <= max_len."""
+    pairs = np.zeros((cap, 2), np.uint32)
+    found = C.c_uint32(0)
+    _check(_lib.drt_debug_hash_cycles(device, max_len, pairs.ctypes.data, cap, C.byref(found)))
+    return [(int(v), int(n)) for v, n in pairs[: min(found.value, cap)]]
 
 
 def debug_check_rcp(device=0):

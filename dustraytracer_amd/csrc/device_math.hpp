@@ -52,11 +52,16 @@ DRT_DEV f3 random_unit_vec3(uint32_t &seed) {                                   
     float z = random_float(seed) * 2.f - 1.f;
     return normalize(mk3(x, y, z));
 }
+// RNG cycle guard: pcg_hash is a permutation of 2^32 with short cycles (lengths 4, 8, 10, 13, 19, 21, 32, ...); a
+// seed that lands on one (RayGen.cuh:91 `seed += i` jumps between cycles) can make every candidate of the two
+// rejection loops fail, and the reference then spins forever.  The loops here stop after kMaxTries candidates and
+// keep the last one (same rule in oracle/drt_oracle.c); 1024 natural rejections in a row have probability < 1e-180.
+constexpr int kMaxTries = 1024;
 DRT_DEV f3 random_unit_sphere_vec3(uint32_t &seed) {                                              // :50-58
-    for (;;) {
+    for (int tries = 1;; tries++) {
         f3 p = random_unit_vec3(seed);
         float len = length(p);
-        if ((len * len) < 1) return p;
+        if ((len * len) < 1 || tries >= kMaxTries) return p;
     }
 }
 // One trip of randomUnitSphereVec3's loop (Random.cu:50-58): candidate p and whether the loop returns it.
@@ -72,11 +77,11 @@ DRT_DEV bool random_unit_sphere_try(uint32_t &seed, f3 &p) {
     return dot(p, p) < 1.0f;
 }
 DRT_DEV f2 random_in_unit_disk(uint32_t &seed) {                                                  // :60-66
-    for (;;) {
+    for (int tries = 1;; tries++) {
         f2 p;
         p.x = random_float(seed) * 2 - 1;
         p.y = random_float(seed) * 2 - 1;
-        if (p.x * p.x + p.y * p.y < 1.0f) return p;
+        if (p.x * p.x + p.y * p.y < 1.0f || tries >= kMaxTries) return p;
     }
 }
 

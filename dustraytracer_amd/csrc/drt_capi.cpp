@@ -545,6 +545,49 @@ int drt_debug_check_rcp(int32_t device, uint64_t *mismatches, uint64_t *fast_pat
     return DRT_OK;
 }
 
+int drt_debug_kat(int32_t device, int32_t which, const void *in, size_t in_bytes, void *out, size_t out_bytes, uint32_t n,
+                  const drt_camera *cam, uint32_t width, uint32_t height) {
+    if (!in || !out || which < 0 || which > 5) return fail(DRT_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    FrameParams fp;
+    std::memset(&fp, 0, sizeof fp);
+    if (which == 4) {
+        if (!cam || width == 0 || height == 0) return fail(DRT_ERR_INVALID, "camera KAT needs a camera and a frame size");
+        drt_renderer tmp;
+        drt_default_settings(&tmp.settings);
+        tmp.width = width; tmp.height = height;
+        fill_frame_params(&tmp, cam, fp);
+    }
+    void *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_in, std::max<size_t>(in_bytes, 16)));
+    hipError_t e = hipMalloc(&d_out, std::max<size_t>(out_bytes, 16));
+    if (e == hipSuccess) e = hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_out, 0, out_bytes);
+    if (e == hipSuccess) e = launch_kat(which, d_in, d_out, n, fp, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(DRT_ERR_DEVICE, hipGetErrorString(e));
+    return DRT_OK;
+}
+
+int drt_debug_hash_cycles(int32_t device, uint32_t max_len, uint32_t *pairs_out, uint32_t cap_pairs, uint32_t *found) {
+    if (!pairs_out || !found || cap_pairs == 0) return fail(DRT_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    uint32_t *d = nullptr;
+    const size_t bytes = (1 + 2 * (size_t)cap_pairs) * sizeof(uint32_t);
+    HIP_TRY(hipMalloc((void **)&d, bytes));
+    hipError_t e = hipMemset(d, 0, bytes);
+    if (e == hipSuccess) e = launch_hash_cycles(max_len, d, cap_pairs, nullptr);
+    std::vector<uint32_t> h(1 + 2 * (size_t)cap_pairs);
+    if (e == hipSuccess) e = hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(DRT_ERR_DEVICE, hipGetErrorString(e));
+    *found = h[0];
+    std::memcpy(pairs_out, h.data() + 1, 2 * (size_t)std::min<uint32_t>(h[0], cap_pairs) * sizeof(uint32_t));
+    return DRT_OK;
+}
+
 int drt_assemble_shards(const void *gathered, void *image, uint32_t width, uint32_t height, uint32_t stripe_rows,
                         uint32_t world, uint32_t padded_rows, void *hip_stream) {
     if (!gathered || !image || stripe_rows == 0 || world == 0) return fail(DRT_ERR_INVALID, "bad argument");

@@ -155,6 +155,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
     f2 tex_uv; tex_uv.x = 0; tex_uv.y = 1;
     uint32_t seed = 0, slot = 0;     // slot: where this sample's colour goes in `samples`
     int bounce = 0;
+    int tries = 0;                   // candidates drawn for the current bounce direction (RNG cycle guard, device_math.hpp)
     // wave-uniform sample pool: chunk = (tile, frame), pool_next = next unassigned sample of the chunk
     uint32_t chunk = 0, pool_next = 64;
     bool exhausted = false;
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
                 // :88 loop condition.  The bounce direction (randomUnitSphereVec3's rejection loop) is drawn one
                 // candidate per R step; after the last bounce the reference still draws one, which nothing reads.
                 stage = (bounce <= fp.bounce_limit) ? kNeedDir : kPathDone;
+                tries = 0;
             }
             // (c) path finished: post-process and park the sample's colour  RayGen.cuh:165-171
             if (in_s && stage == kPathDone) {
@@ -317,7 +319,8 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
             if (COUNT) { d_exec[3]++; d_lanes[3] += (unsigned long long)n_r; }
             if (!(cur < end) && !(sp > 0) && stage == kNeedDir) {
                 f3 p;
-                if (random_unit_sphere_try(seed, p)) {
+                const bool accepted = random_unit_sphere_try(seed, p);
+                if (accepted || ++tries >= kMaxTries) {
                     ray = make_ray(bounce_origin, bounce_normal + p);
                     begin_closest();
                     stage = kTraceDone;
@@ -437,6 +440,23 @@ __global__ __launch_bounds__(256) void check_rcp_kernel(uint32_t first, unsigned
     if (fast) atomicAdd(fast_path, fast);
 }
 
+// Debug: finds every 32-bit value that lies on a cycle of pcg_hash (Random.cu:6-11) of length <= max_len.
+// out[0] = number found, then (value, cycle length) pairs.
+__global__ __launch_bounds__(256) void hash_cycles_kernel(uint32_t max_len, uint32_t *out, uint32_t cap_pairs) {
+    for (unsigned long long k = (unsigned long long)blockIdx.x * 256u + threadIdx.x; k < (1ull << 32); k += (unsigned long long)gridDim.x * 256u) {
+        const uint32_t x = (uint32_t)k;
+        uint32_t y = x;
+        for (uint32_t len = 1; len <= max_len; len++) {
+            y = pcg_hash(y);
+            if (y == x) {
+                const uint32_t slot = atomicAdd(out, 1u);
+                if (slot < cap_pairs) { out[1 + 2 * slot] = x; out[2 + 2 * slot] = len; }
+                break;
+            }
+        }
+    }
+}
+
 template <int STACK, int MODE, bool LDS_SCENE>
 hipError_t launch_one(const SceneView &sc, const FrameParams &fp, unsigned int *chunk_counter, float4 *samples,
                       size_t lds_bytes, int num_cus, hipStream_t stream) {
@@ -480,6 +500,11 @@ hipError_t launch_stack(const SceneView &sc, const FrameParams &fp, int mode, bo
 
 hipError_t launch_check_rcp(uint32_t first_bits, unsigned long long count, unsigned long long *d_out2, hipStream_t stream) {
     hipLaunchKernelGGL(check_rcp_kernel, dim3(4096), dim3(256), 0, stream, first_bits, count, d_out2, d_out2 + 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_hash_cycles(uint32_t max_len, uint32_t *d_out, uint32_t cap_pairs, hipStream_t stream) {
+    hipLaunchKernelGGL(hash_cycles_kernel, dim3(8192), dim3(256), 0, stream, max_len, d_out, cap_pairs);
     return hipGetLastError();
 }
 

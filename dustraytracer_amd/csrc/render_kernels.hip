@@ -244,6 +244,45 @@ __global__ __launch_bounds__(kBlockThreads) void pixel_walk_kernel(const SceneVi
     }
 }
 
+// Known-answer tests of the device leaf functions (drt_debug_kat): the inputs/outputs are the ones of
+// tests/golden/kat_ref.npz, which was produced by the reference's own compiled sources.
+__global__ __launch_bounds__(256) void kat_kernel(int which, const uint32_t *in, uint32_t *out, uint32_t n, const FrameParams fp) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float *fin = reinterpret_cast<const float *>(in);
+    float *fout = reinterpret_cast<float *>(out);
+    if (which == 0 || which == 1) {             // in: seed -> out: vec3, seed [, tries]   (0 = unit vec, 1 = unit sphere)
+        uint32_t seed = in[i];
+        f3 p; uint32_t tries = 1;
+        if (which == 0) p = random_unit_vec3(seed);
+        else { for (;; tries++) { if (random_unit_sphere_try(seed, p) || tries >= (uint32_t)kMaxTries) break; } }
+        fout[5 * i] = p.x; fout[5 * i + 1] = p.y; fout[5 * i + 2] = p.z; out[5 * i + 3] = seed; out[5 * i + 4] = tries;
+    } else if (which == 2) {                    // in: orig3, dir3, min3, max3 -> out: slab distance
+        const float *r = fin + 12 * i;
+        const Ray ray = make_ray(mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]));
+        fout[i] = slab_intersect(mk3(r[6], r[7], r[8]), mk3(r[9], r[10], r[11]), ray);
+    } else if (which == 3) {                    // in: orig3, dir3, v0, v1, v2 -> out: t, U, V, W, hit (straight-line test)
+        const float *r = fin + 15 * i;
+        const Ray ray = make_ray(mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]));
+        const f3 v0 = mk3(r[6], r[7], r[8]);
+        const f3 e1 = mk3(r[9], r[10], r[11]) - v0, e2 = mk3(r[12], r[13], r[14]) - v0;
+        float t, u, v;
+        const bool h = tri_intersect_flat(ray, v0, e1, e2, t, u, v);
+        fout[5 * i] = h ? t : -1.0f; fout[5 * i + 1] = h ? 1.0f - u - v : 0.f; fout[5 * i + 2] = h ? u : 0.f; fout[5 * i + 3] = h ? v : 0.f;
+        out[5 * i + 4] = h ? 1u : 0u;
+    } else if (which == 4) {                    // in: u, v, seed -> out: orig3, dir3, seed  (camera constants in fp)
+        f2 uv; uv.x = fin[3 * i]; uv.y = fin[3 * i + 1];
+        uint32_t seed = in[3 * i + 2];
+        const Ray ray = camera_get_ray(fp, uv, seed);
+        fout[7 * i] = ray.orig.x; fout[7 * i + 1] = ray.orig.y; fout[7 * i + 2] = ray.orig.z;
+        fout[7 * i + 3] = ray.dir.x; fout[7 * i + 4] = ray.dir.y; fout[7 * i + 5] = ray.dir.z; out[7 * i + 6] = seed;
+    } else if (which == 5) {                    // in: seed -> out: disk2, seed
+        uint32_t seed = in[i];
+        const f2 p = random_in_unit_disk(seed);
+        fout[3 * i] = p.x; fout[3 * i + 1] = p.y; out[3 * i + 2] = seed;
+    }
+}
+
 // rank-0 side of the gather: shard r, local row ly  ->  image row y
 __global__ void assemble_shards_kernel(const float4 *gathered, float4 *image, uint32_t width, uint32_t height,
                                        uint32_t stripe_rows, uint32_t world, uint32_t padded_rows) {
@@ -274,6 +313,12 @@ hipError_t launch_render(const SceneView &sc, const FrameParams &fp, int bvh_dep
     if (bvh_depth <= 32) { if (kernel_name) *kernel_name = "pixel_walk<stack32>"; return launch_stack<32>(sc, fp, count, stream); }
     if (bvh_depth <= 64) { if (kernel_name) *kernel_name = "pixel_walk<stack64>"; return launch_stack<64>(sc, fp, count, stream); }
     return hipErrorInvalidValue;     // the reference's own stack is 64 deep (BVHTraversal.cuh:17)
+}
+
+hipError_t launch_kat(int which, const void *d_in, void *d_out, uint32_t n, const FrameParams &fp, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(kat_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, which, (const uint32_t *)d_in, (uint32_t *)d_out, n, fp);
+    return hipGetLastError();
 }
 
 hipError_t launch_assemble(const void *gathered, void *image, uint32_t width, uint32_t height, uint32_t stripe_rows,

@@ -22,6 +22,12 @@ hipError_t launch_wave_queue(const SceneView &scene, const FrameParams &frame, i
 // debug: d_out2[0] += #floats in [first_bits, first_bits+count) where exact_rcp != 1.0f/x, d_out2[1] += #floats on its fast path
 hipError_t launch_check_rcp(uint32_t first_bits, unsigned long long count, unsigned long long *d_out2, hipStream_t stream);
 
+// debug: all values on pcg_hash cycles of length <= max_len; d_out = [count, (value, length) x cap_pairs]
+hipError_t launch_hash_cycles(uint32_t max_len, uint32_t *d_out, uint32_t cap_pairs, hipStream_t stream);
+
+// debug: device leaf functions on arrays (which: 0 unit vec, 1 unit sphere, 2 slab, 3 triangle, 4 camera ray, 5 unit disk)
+hipError_t launch_kat(int which, const void *d_in, void *d_out, uint32_t n, const FrameParams &frame, hipStream_t stream);
+
 hipError_t launch_assemble(const void *gathered, void *image, uint32_t width, uint32_t height, uint32_t stripe_rows,
                            uint32_t world, uint32_t padded_rows, hipStream_t stream);
 

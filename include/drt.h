@@ -181,6 +181,14 @@ int           drt_assemble_shards(const void *gathered, void *image, uint32_t wi
                                   uint32_t stripe_rows, uint32_t world, uint32_t padded_rows, void *hip_stream);
 /* Self-check of the kernels' reciprocal (device_math.hpp exact_rcp) against IEEE 1.0f/x over all 2^32 float bit patterns. */
 int           drt_debug_check_rcp(int32_t device, uint64_t *mismatches, uint64_t *fast_path_count);
+/* Device leaf functions on arrays, for known-answer tests against tests/golden/kat_ref.npz.
+ * which: 0 unit vec (in u32 seed; out vec3,seed,tries), 1 unit sphere (same), 2 slab (in orig3,dir3,min3,max3; out f32),
+ * 3 triangle (in orig3,dir3,v0,v1,v2; out t,U,V,W,hit), 4 camera ray (in u,v,seed; out orig3,dir3,seed; needs cam,width,height),
+ * 5 unit disk (in seed; out x,y,seed). */
+int           drt_debug_kat(int32_t device, int32_t which, const void *in, size_t in_bytes, void *out, size_t out_bytes, uint32_t n,
+                            const drt_camera *cam, uint32_t width, uint32_t height);
+/* Every 32-bit value on a cycle of the RNG hash (Random.cu:6-11) no longer than max_len: (value, length) pairs. */
+int           drt_debug_hash_cycles(int32_t device, uint32_t max_len, uint32_t *pairs_out, uint32_t cap_pairs, uint32_t *found);
 uint32_t      drt_shard_rows(uint32_t height, uint32_t stripe_rows, uint32_t rank, uint32_t world);
 
 #ifdef __cplusplus

@@ -20,6 +20,12 @@
  *  - std::powf(x, 2) := x * x      (RayGen.cuh:59, Texture.cu:56).
  *  - tan/sin/cos of per-frame constants use the host libm (tanf/sinf/cosf),
  *    hoisted out of the per-pixel code (Camera.cu:85,101; RayGen.cuh:68-71).
+ *  - RNG cycle guard.  pcg_hash is a permutation of 2^32 with short cycles (lengths 4, 8, 10, 13, 19, ...;
+ *    found exhaustively on the GPU, drt_debug_hash_cycles).  `seed += i` (RayGen.cuh:91) can land on one,
+ *    and on some of them every candidate of randomUnitSphereVec3 / random_in_unit_disk is rejected: the
+ *    reference then never returns (at 4K x 64 spp x depth 16 this is expected to happen about twice per
+ *    image).  Both loops stop after DRT_MAX_TRIES candidates and return the last one; a natural run of that
+ *    many rejections has probability < 1e-180, so no terminating reference path is changed.
  *  - Texture::getPixel can index one texel row past the image when
  *    frac(uv) rounds to 1.0 (Texture.cu:35-36): textures carry (width+1)
  *    texels of zero padding so the read is defined.
@@ -92,25 +98,27 @@ static inline f3 random_unit_vec3(uint32_t *seed)                               
     return normalize3(v3(x, y, z));
 }
 
+#define DRT_MAX_TRIES 1024                   /* RNG cycle guard, see the header comment */
+
 static inline f3 random_unit_sphere_vec3(uint32_t *seed, uint64_t *iters)                   /* :50-58 */
 {
-    for (;;) {
+    for (int tries = 1;; tries++) {
         f3 p = random_unit_vec3(seed);
         float len = length3(p);
         if (iters) ++*iters;
         trace('R');
-        if ((len * len) < 1)
+        if ((len * len) < 1 || tries >= DRT_MAX_TRIES)
             return p;
     }
 }
 
 static inline f2 random_in_unit_disk(uint32_t *seed)                                        /* :60-66 */
 {
-    for (;;) {
+    for (int tries = 1;; tries++) {
         f2 p;
         p.x = random_float(seed) * 2 - 1;
         p.y = random_float(seed) * 2 - 1;
-        if (p.x * p.x + p.y * p.y < 1.0f)
+        if (p.x * p.x + p.y * p.y < 1.0f || tries >= DRT_MAX_TRIES)
             return p;
     }
 }
