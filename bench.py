@@ -58,17 +58,17 @@ def cpu_baseline(scene_key, W, H, depth, target_seconds):
     osc = oracle.Scene.load_glb(scene_path(scene_key)).build_bvh(20, 8)
     cam = oracle.default_camera(position=pos, forward=fwd)
     st = oracle.default_settings(ray_bounce_limit=depth)
-    # calibrate on 1/16 of the rows at 1 spp, then size the real sample to ~target_seconds
+    # calibrate on every 4th stripe at 1 spp (enough work to amortise thread start-up), then size the real sample
     t0 = time.perf_counter()
-    oracle.render(osc, cam, st, W, H, 1, 1, threads=cores, stripe_rows=STRIPE_ROWS, rank=0, world=16)
+    oracle.render(osc, cam, st, W, H, 1, 1, threads=cores, stripe_rows=STRIPE_ROWS, rank=0, world=4)
     dt = max(time.perf_counter() - t0, 1e-4)
-    rows = sum(min(STRIPE_ROWS, H - s * STRIPE_ROWS) for s in range(0, (H + STRIPE_ROWS - 1) // STRIPE_ROWS, 16))
+    rows = sum(min(STRIPE_ROWS, H - s * STRIPE_ROWS) for s in range(0, (H + STRIPE_ROWS - 1) // STRIPE_ROWS, 4))
     rate = rows * W / dt
-    # sample = every `world`-th stripe of the frame at `frames` spp
+    # sample = every `world`-th stripe of the frame, frame indices 1..frames (per-sample cost does not depend on the index)
     want = rate * target_seconds
     full = W * H
     if want >= full:
-        world, frames = 1, max(1, min(8, int(want // full)))
+        world, frames = 1, max(1, min(256, int(want // full)))
     else:
         world, frames = max(1, min(64, int(round(full / want)))), 1
     t0 = time.perf_counter()

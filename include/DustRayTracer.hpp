@@ -1,0 +1,189 @@
+// DustRayTracer.hpp -- the reference's "intended library header" (DustRayTracer/include/DustRayTracer.hpp:1 is empty)
+// filled in for the MI355X core: thin C++ classes with the reference's names and members over the C ABI of drt.h.
+//
+//   Renderer        Core/Renderer.hpp:14-47          ResizeBuffer / Render / resetAccumulationBuffer / getSampleCount /
+//                                                    getBufferWidth / getBufferHeight / public m_RendererSettings
+//   Scene           Core/Scene/Scene.cuh:41-57       loadGLTFmodel (+ counts the editor shows, EditorLayer.cpp:57-65)
+//   BVHBuilder      Core/BVH/BVHBuilder.cuh:12-23    m_BinCount, m_TargetLeafPrimitivesCount, buildIterative, build
+//   Camera          Core/Scene/Camera.cuh:14-48      public fields, OnUpdate, Rotate, GetPosition
+//   RendererSettings Core/Scene/RendererSettings.h   same fields and enums
+//
+// Differences a caller sees (INTEGRATION.md lists the editor-side edits):
+//   * no GL interop: GetRenderTargetImage_name() is replaced by ReadRenderTarget(float*) / DeviceRenderTarget();
+//   * Camera is a plain host object (no cudaMallocManaged `Managed` base), copied by value at each Render;
+//   * errors throw drt::Error instead of printing and exit(99) (Editor/Common/CudaCommon.cu:4-13).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "drt.h"
+
+namespace drt {
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const char *msg) : std::runtime_error(msg ? msg : "drt error"), code(c) {}
+};
+inline void check(int rc) { if (rc < 0) throw Error(rc, drt_last_error()); }
+}  // namespace drt
+
+struct float3_ { float x, y, z; };      // stand-in for CUDA's float3 in this header's public fields
+struct float4_ { float x, y, z, w; };
+
+// Core/Scene/RendererSettings.h:4-35
+struct RendererSettings {
+    enum class RenderModes { NORMALMODE = 0, DEBUGMODE = 1 };
+    enum class DebugModes { ALBEDO_DEBUG = 0, NORMAL_DEBUG = 1, BARYCENTRIC_DEBUG = 2, UVS_DEBUG = 3, MESHBVH_DEBUG = 4, WORLDBVH_DEBUG = 5 };
+    bool gamma_correction = true;
+    bool tone_mapping = true;
+    bool enableSunlight = false;
+    int max_samples = 500;
+    int ray_bounce_limit = 2;
+    RenderModes RenderMode = RenderModes::NORMALMODE;
+    DebugModes DebugMode = DebugModes::ALBEDO_DEBUG;
+    float sunlight_dir[2] = { -0.803f, 0.681f };
+    float3_ sunlight_color = { 1.000f, 0.944f, 0.917f };
+    float sunlight_intensity = 30;
+    float3_ sky_color = { 0.25f, 0.498f, 0.80f };
+    float sky_intensity = 20;
+
+    drt_settings pod() const {
+        drt_settings s;
+        s.gamma_correction = gamma_correction; s.tone_mapping = tone_mapping; s.enable_sunlight = enableSunlight;
+        s.max_samples = max_samples; s.ray_bounce_limit = ray_bounce_limit;
+        s.render_mode = (int)RenderMode; s.debug_mode = (int)DebugMode;
+        s.sunlight_dir[0] = sunlight_dir[0]; s.sunlight_dir[1] = sunlight_dir[1];
+        s.sunlight_color[0] = sunlight_color.x; s.sunlight_color[1] = sunlight_color.y; s.sunlight_color[2] = sunlight_color.z;
+        s.sunlight_intensity = sunlight_intensity;
+        s.sky_color[0] = sky_color.x; s.sky_color[1] = sky_color.y; s.sky_color[2] = sky_color.z;
+        s.sky_intensity = sky_intensity;
+        return s;
+    }
+};
+
+inline float deg2rad(float degree) { const float PI = 3.14159265359f; return degree * (PI / 180.f); }    // Camera.cu:125-129
+
+// Core/Scene/Camera.cuh:14-48
+class Camera {
+public:
+    explicit Camera(float3_ pos = { 0, 2, 5 }) : m_Position(pos) { m_Right_dir = cross(m_Forward_dir, m_Up_dir); }
+
+    void OnUpdate(float3_ velocity, float delta) {                       // Camera.cu:44-58
+        float3_ v = { m_Right_dir.x * velocity.x + m_Up_dir.x * velocity.y + m_Forward_dir.x * velocity.z,
+                      m_Right_dir.y * velocity.x + m_Up_dir.y * velocity.y + m_Forward_dir.y * velocity.z,
+                      m_Right_dir.z * velocity.x + m_Up_dir.z * velocity.y + m_Forward_dir.z * velocity.z };
+        m_Position = { m_Position.x + m_movement_speed * v.x * delta, m_Position.y + m_movement_speed * v.y * delta,
+                       m_Position.z + m_movement_speed * v.z * delta };
+    }
+    void Rotate(float4_ d) {                                             // Camera.cu:61-80 (sin_x, cos_x, sin_y, cos_y)
+        m_Forward_dir = rodrigues(m_Forward_dir, m_Up_dir, d.x, d.y);
+        m_Forward_dir = rodrigues(m_Forward_dir, m_Right_dir, d.z, d.w);
+        m_Right_dir = cross(m_Forward_dir, m_Up_dir);
+    }
+    float3_ GetPosition() const { return m_Position; }
+    void setMovementSpeed(float speed) { m_movement_speed = speed; }
+
+    float exposure = 1;
+    float vfov_rad = deg2rad(60);
+    float zfar = 0, znear = 0, m_AspectRatio = 0;
+    float defocus_angle = 0;
+    float focus_dist = 10;
+    float m_movement_speed = 10;
+    float3_ m_Position = { 0, 2, 5 };
+    float3_ m_Forward_dir = { 0, 0, -1 };
+    float3_ m_Up_dir = { 0, 1, 0 };
+    float3_ m_Right_dir = { 0, 1, 0 };
+
+    drt_camera pod() const {
+        drt_camera c;
+        c.exposure = exposure; c.vfov_rad = vfov_rad; c.defocus_angle = defocus_angle; c.focus_dist = focus_dist;
+        c.position[0] = m_Position.x; c.position[1] = m_Position.y; c.position[2] = m_Position.z;
+        c.forward[0] = m_Forward_dir.x; c.forward[1] = m_Forward_dir.y; c.forward[2] = m_Forward_dir.z;
+        return c;
+    }
+
+private:
+    static float3_ cross(float3_ a, float3_ b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+    static float dot(float3_ a, float3_ b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+    static float3_ rodrigues(float3_ v, float3_ k, float s, float c) {
+        float3_ kxv = cross(k, v);
+        float kv = dot(k, v) * (1 - c);
+        return { v.x * c + kxv.x * s + k.x * kv, v.y * c + kxv.y * s + k.y * kv, v.z * c + kxv.z * s + k.z * kv };
+    }
+};
+
+// Core/Scene/Scene.cuh:41-57
+struct Scene {
+    Scene() : handle(drt_scene_create()) { if (!handle) throw drt::Error(DRT_ERR_INVALID, drt_last_error()); }
+    ~Scene() { drt_scene_destroy(handle); }
+    Scene(const Scene &) = delete;
+    Scene &operator=(const Scene &) = delete;
+
+    bool loadGLTFmodel(const char *filepath) { drt::check(drt_scene_load_gltf(handle, filepath)); return true; }
+
+    // what the editor's metrics panel reads from m_Meshes / m_Material / m_Textures (EditorLayer.cpp:57-65)
+    size_t meshCount() const { return (size_t)drt_scene_mesh_count(handle); }
+    size_t trianglesCount() const { return (size_t)drt_scene_triangle_count(handle); }
+    size_t materialsCount() const { return (size_t)drt_scene_material_count(handle); }
+    size_t texturesCount() const { return (size_t)drt_scene_texture_count(handle); }
+    std::vector<drt_triangle> primitives() const {                        // m_PrimitivesBuffer
+        std::vector<drt_triangle> v(trianglesCount());
+        if (!v.empty()) drt::check(drt_scene_get_triangles(handle, v.data(), (int32_t)v.size()));
+        return v;
+    }
+    std::vector<drt_bvh_node> bvhNodes() const {                          // m_BVHNodes (root last)
+        std::vector<drt_bvh_node> v((size_t)drt_scene_node_count(handle));
+        if (!v.empty()) drt::check(drt_scene_get_nodes(handle, v.data(), (int32_t)v.size()));
+        return v;
+    }
+
+    drt_scene *handle;
+};
+
+// Core/BVH/BVHBuilder.cuh:12-23
+class BVHBuilder {
+public:
+    int m_BinCount = 8;
+    int m_TargetLeafPrimitivesCount = 6;
+    // the reference passes (scene.m_PrimitivesBuffer, scene.m_BVHNodes) and stores the returned root pointer
+    // (EditorLayer.cpp:55); here the scene owns both, so the scene is the argument.
+    void buildIterative(Scene &scene) { drt::check(drt_scene_build_bvh(scene.handle, m_TargetLeafPrimitivesCount, m_BinCount)); }
+    void build(Scene &scene) { buildIterative(scene); }                   // BVHBuilder.cu:100-173: same tree via recursion
+};
+
+// Core/Renderer.hpp:14-47
+class Renderer {
+public:
+    explicit Renderer(int device = 0) : handle(drt_renderer_create(device)) { if (!handle) throw drt::Error(DRT_ERR_DEVICE, drt_last_error()); }
+    ~Renderer() { drt_renderer_destroy(handle); }
+    Renderer(const Renderer &) = delete;
+    Renderer &operator=(const Renderer &) = delete;
+
+    void ResizeBuffer(uint32_t width, uint32_t height) { drt::check(drt_renderer_resize(handle, width, height)); }
+    void Render(Camera *cam, const Scene &scene, float *delta) {
+        drt_settings s = m_RendererSettings.pod();
+        drt::check(drt_renderer_set_settings(handle, &s));
+        drt_camera c = cam->pod();
+        drt::check(drt_renderer_render(handle, &c, scene.handle, delta));
+    }
+    // spp batch: frames getSampleCount() .. +n-1 in one launch, same image as n Render() calls
+    void RenderBatch(Camera *cam, const Scene &scene, uint32_t n_frames, float *delta) {
+        drt_settings s = m_RendererSettings.pod();
+        drt::check(drt_renderer_set_settings(handle, &s));
+        drt_camera c = cam->pod();
+        drt::check(drt_renderer_render_batch(handle, &c, scene.handle, n_frames, delta));
+    }
+    uint32_t getBufferWidth() const { return drt_renderer_width(handle); }
+    uint32_t getBufferHeight() const { return drt_renderer_height(handle); }
+    uint32_t getSampleCount() const { return drt_renderer_sample_count(handle); }
+    void resetAccumulationBuffer() { drt::check(drt_renderer_reset(handle)); }
+
+    // replaces GLuint& GetRenderTargetImage_name(): RGBA32F, row 0 = bottom, width*height*4 floats
+    void ReadRenderTarget(float *dst) { drt::check(drt_renderer_read_rgba32f(handle, dst, (size_t)getBufferWidth() * drt_renderer_local_rows(handle) * 4)); }
+    void *DeviceRenderTarget() { return drt_renderer_device_rgba(handle); }
+
+    RendererSettings m_RendererSettings;
+    drt_renderer *handle;
+};
