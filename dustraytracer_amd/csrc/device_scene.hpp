@@ -98,7 +98,7 @@ struct FrameParams {
     float *rgba;                     // float4[width*local_rows]
     unsigned long long *counters;    // drt_counters as 18 x u64, or nullptr
     // wave_queue phase voting: a phase other than T runs as soon as this many lanes wait for it
-    int32_t vote_node, vote_shade, vote_dir;
+    int32_t vote_node, vote_shade, vote_dir, vote_spec;
 };
 
 }  // namespace drt

@@ -14,10 +14,16 @@
 //   * ORDERED RESOLVE.  Each sample's colour goes to a float4 slot [frame][pixel] in HBM; resolve_kernel then
 //     adds the frames of a pixel in frame order, ((a + c_f) + c_f+1) + ..., exactly the order of
 //     accumulation_buffer += fcolor over successive launches (RenderKernel.cu:29-30), and writes accum + RGBA.
-//   * PHASE VOTING.  A lane is in one of four states: T = has a leaf triangle to test, N = has a node on its
-//     stack, R = needs a try of the bounce-direction rejection sampler, S = needs shading / a new sample.
-//     The wave loop ballots the states and runs ONE phase for all lanes in that state; T (one Moller-Trumbore
-//     test per lane, the dominant work) keeps running until enough lanes wait for another phase.
+//   * PHASE VOTING.  A lane is in one of three traversal/shading states: T = has a leaf triangle to test, N = has a
+//     node on its stack, S = needs shading / a new ray / a new sample.  The wave loop ballots the states and runs
+//     ONE phase for all lanes in that state; T (one Moller-Trumbore test per lane, the dominant work) keeps running
+//     until enough lanes wait for another phase.
+//   * SPECULATIVE BOUNCE DIRECTIONS (phase R).  randomUnitSphereVec3 is a rejection loop (~2.9 tries, Random.cu:50-58)
+//     whose draws depend only on the seed, not on what the ray hits.  As soon as a ray is launched, the lane knows
+//     the seed its bounce direction will be drawn from (RayGen.cuh:91 seed += i), so the tries run in the BACKGROUND,
+//     one candidate per R step, for every lane with a direction pending -- whatever its traversal state -- and a
+//     hit usually finds its direction ready.  If the ray misses, the direction is simply dropped (the reference never
+//     draws it); the RNG stream seen by the path is unchanged.
 //   * LDS.  Traversal stack (node reference + entry distance, 8 B) per lane in LDS, entry [level][tid]:
 //     conflict-free for ds_read/write_b64.  For scenes whose traversal data (child-box-pair records, leaf
 //     ranges, TriHot records) fits kLdsSceneBytes, every workgroup stages it in LDS once and all node /
@@ -26,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "device_access.hpp"
 #include "device_math.hpp"
@@ -37,6 +44,10 @@ namespace drt {
 namespace {
 
 constexpr int kThreads = 256;
+#ifndef DRT_TRIS_PER_STEP
+#define DRT_TRIS_PER_STEP 2
+#endif
+constexpr int kTrianglesPerStep = DRT_TRIS_PER_STEP;      // lean kernel only
 
 // per-lane path stage: what the S phase has to do next for this lane (kNeedDir lanes are served by R)
 enum : int { kNeedSample = 0, kTraceDone = 2, kShadowDone = 3, kFinished = 4, kPathDone = 5, kNeedDir = 6 };
@@ -156,6 +167,9 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
     uint32_t seed = 0, slot = 0;     // slot: where this sample's colour goes in `samples`
     int bounce = 0;
     int tries = 0;                   // candidates drawn for the current bounce direction (RNG cycle guard, device_math.hpp)
+    int spec = 0;                    // bounce direction: 0 not requested, 1 pending (R steps work on it), 2 ready
+    uint32_t spec_seed = 0;          // RNG state of the direction's draws (becomes `seed` when the direction is used)
+    f3 spec_p = mk3(0, 0, 0);
     // wave-uniform sample pool: chunk = (tile, frame), pool_next = next unassigned sample of the chunk
     uint32_t chunk = 0, pool_next = 64;
     bool exhausted = false;
@@ -174,12 +188,21 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
         }
     };
 
+    // After launching the ray of bounce index `bounce`: its hit will need a direction drawn from seed + bounce
+    // (RayGen.cuh:91 then :134), unless sunlight draws come first (then the direction is requested at the hit).
+    auto arm_direction = [&]() {
+        if (!debug && !sun && bounce < fp.bounce_limit) { spec = 1; spec_seed = seed + (uint32_t)bounce; tries = 0; }
+        else spec = 0;
+    };
+
     // Wave loop.  One trip = maybe S, then R steps, then N steps, then T steps; every inner loop stops as soon as
     // its own supply of lanes is low and another phase has enough lanes waiting (thresholds vote_*).
     for (;;) {
         // class masks (scalar): a lane is T if it has triangles, else N if it has stack entries, else R / S by stage
         unsigned long long m_t = ballot(cur < end), m_sp = ballot(sp > 0);
-        unsigned long long m_dir = ballot(stage == kNeedDir), m_fin = ballot(stage == kFinished);
+        // m_dir: lanes BLOCKED on their bounce direction (hit shaded, direction not ready yet); m_pend: direction pending
+        unsigned long long m_dir = ballot(stage == kNeedDir && spec != 2), m_fin = ballot(stage == kFinished);
+        unsigned long long m_pend = ballot(spec == 1);
         unsigned long long m_n = ~m_t & m_sp, m_idle = ~m_t & ~m_sp;
         unsigned long long m_r = m_idle & m_dir, m_s = m_idle & ~m_dir & ~m_fin;
         if ((m_t | m_n | m_r | m_s) == 0) break;
@@ -188,7 +211,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
         const int n_s = __popcll(m_s);
         if (n_s >= vote_shade || (m_t == 0 && m_n == 0 && n_s > 0 && n_s >= __popcll(m_r))) {
             if (COUNT) { d_exec[2]++; d_lanes[2] += (unsigned long long)n_s; }
-            const bool in_s = !(cur < end) && !(sp > 0) && stage != kNeedDir && stage != kFinished;
+            const bool in_s = !(cur < end) && !(sp > 0) && !(stage == kNeedDir && spec != 2) && stage != kFinished;
             // (a) a closest-hit traversal finished: RayGen.cuh:90-134
             if (in_s && stage == kTraceDone) {
                 seed += (uint32_t)bounce;                                                  // :91
@@ -238,7 +261,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
                         path_done = true;
                     }
                 }
-                if (path_done) { stage = kPathDone; sp = 0; cur = end = 0; }
+                if (path_done) { stage = kPathDone; sp = 0; cur = end = 0; spec = 0; }
             }
             // (b) the sun shadow traversal (if any) is over: add sunlight, ask for a bounce direction  RayGen.cuh:126-134
             if (in_s && stage == kShadowDone && sp == 0) {
@@ -246,8 +269,21 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
                 ++bounce;
                 // :88 loop condition.  The bounce direction (randomUnitSphereVec3's rejection loop) is drawn one
                 // candidate per R step; after the last bounce the reference still draws one, which nothing reads.
-                stage = (bounce <= fp.bounce_limit) ? kNeedDir : kPathDone;
-                tries = 0;
+                if (bounce <= fp.bounce_limit) {
+                    stage = kNeedDir;
+                    if (spec == 0) { spec = 1; spec_seed = seed; tries = 0; }              // not drawn in the background: request it now
+                } else {
+                    stage = kPathDone;
+                    spec = 0;
+                }
+            }
+            // (b2) direction ready: launch the bounce ray  RayGen.cuh:133-134
+            if (in_s && stage == kNeedDir && spec == 2) {
+                seed = spec_seed;
+                ray = make_ray(bounce_origin, bounce_normal + spec_p);
+                begin_closest();
+                stage = kTraceDone;
+                arm_direction();
             }
             // (c) path finished: post-process and park the sample's colour  RayGen.cuh:165-171
             if (in_s && stage == kPathDone) {
@@ -303,32 +339,33 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
                     if (COUNT) c_samples++;
                     begin_closest();
                     stage = kTraceDone;
+                    arm_direction();
                 }
                 // a sample outside the image (partial tile) leaves the lane in kNeedSample: it asks again next time
             }
             m_sp = ballot(sp > 0);
-            m_dir = ballot(stage == kNeedDir); m_fin = ballot(stage == kFinished);
+            m_dir = ballot(stage == kNeedDir && spec != 2); m_fin = ballot(stage == kFinished);
+            m_pend = ballot(spec == 1);
         }
 
-        // ================= R: one candidate of the bounce direction per waiting lane (Random.cu:50-58, RayGen.cuh:133-134) ====
+        // ================= R: one candidate of the bounce direction for every lane that has one pending
+        //                    (Random.cu:50-58, drawn ahead of RayGen.cuh:133-134) =================
         for (;;) {
-            m_r = ~m_t & ~m_sp & m_dir;
-            const int n_r = __popcll(m_r);
-            if (n_r == 0) break;
-            if (n_r < vote_dir && (m_t | (~m_t & m_sp)) != 0) break;
-            if (COUNT) { d_exec[3]++; d_lanes[3] += (unsigned long long)n_r; }
-            if (!(cur < end) && !(sp > 0) && stage == kNeedDir) {
+            const int n_pend = __popcll(m_pend);
+            if (n_pend == 0) break;
+            const int n_block = __popcll(~m_t & ~m_sp & m_dir);
+            // run when enough directions are pending, when enough lanes are blocked on theirs, or when nothing else can run
+            if (n_pend < fp.vote_spec && n_block < vote_dir && !(n_block > 0 && (m_t | (~m_t & m_sp)) == 0)) break;
+            if (COUNT) { d_exec[3]++; d_lanes[3] += (unsigned long long)n_pend; }
+            if (spec == 1) {
                 f3 p;
-                const bool accepted = random_unit_sphere_try(seed, p);
-                if (accepted || ++tries >= kMaxTries) {
-                    ray = make_ray(bounce_origin, bounce_normal + p);
-                    begin_closest();
-                    stage = kTraceDone;
-                }
+                const bool accepted = random_unit_sphere_try(spec_seed, p);
+                if (accepted || ++tries >= kMaxTries) { spec_p = p; spec = 2; }
             }
-            m_sp = ballot(sp > 0);
-            m_dir = ballot(stage == kNeedDir);
+            m_pend = ballot(spec == 1);
+            m_dir = ballot(stage == kNeedDir && spec != 2);
         }
+        // lanes whose direction just became ready are S lanes now; they are picked up by the next trip's S vote
 
         // ================= N: pop one stack entry per waiting lane (BVHTraversal.cuh:33-72 / :91-131) =================
         for (;;) {
@@ -377,7 +414,23 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
             if (__popcll(~m_t & m_sp) >= vote_node || __popcll(idle & m_dir) >= vote_dir ||
                 __popcll(idle & ~m_dir & ~m_fin) >= vote_shade) break;
             if (COUNT) { d_exec[0]++; d_lanes[0] += (unsigned long long)__popcll(m_t); }
-            if (cur < end) {
+            if (!GENERAL && kTrianglesPerStep == 2) {
+                // lean variant: two consecutive triangles of the leaf per step (both loads in flight together, two
+                // independent dependency chains to interleave); hits are applied in leaf order, so ties resolve as in
+                // the one-at-a-time loop.  A lane with one triangle left tests it twice and ignores the second result.
+                if (cur < end) {
+                    const int i = cur;
+                    const bool two = i + 1 < end;
+                    const int j = two ? i + 1 : i;
+                    cur = j + 1;
+                    const TriTest ta = fetch_tri(i), tb = fetch_tri(j);
+                    float t0, u0, v0, t1, u1, v1;
+                    const bool h0 = tri_intersect_flat(ray, ta.v0, ta.e1, ta.e2, t0, u0, v0);
+                    const bool h1 = tri_intersect_flat(ray, tb.v0, tb.e1, tb.e2, t1, u1, v1) & two;
+                    if (h0 && t0 < hit_t) { hit_t = t0; hit_prim = i; hit_u = u0; hit_v = v0; }
+                    if (h1 && t1 < hit_t) { hit_t = t1; hit_prim = j; hit_u = u1; hit_v = v1; }
+                }
+            } else if (cur < end) {
                 const int i = cur++;
                 const TriTest tri = fetch_tri(i);
                 float t, u, v;
@@ -474,6 +527,7 @@ hipError_t launch_one(const SceneView &sc, const FrameParams &fp, unsigned int *
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kThreads, lds_bytes) != hipSuccess || n < 1) n = 1;
         per_cu_cache = std::min(n, 8);
+        if (const char *cap = std::getenv("DRT_MAX_BLOCKS_PER_CU")) per_cu_cache = std::max(1, std::min(per_cu_cache, std::atoi(cap)));
         per_cu_lds = lds_bytes;
     }
     const uint64_t n_chunks = (uint64_t)tiles_x * tiles_y * fp.n_frames;

@@ -257,6 +257,50 @@ def test_external_buffers_and_stream():
     compare(rgba.cpu().numpy(), ref, "external buffers")
 
 
+def _render_with_env(env, name, W, H, frames, depth):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        r = drt.Renderer(0)                     # the knobs are read when the renderer is created
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    sc, osc = make_pair(name)
+    cam, ocam = cameras(name)
+    s, o = settings_pair(ray_bounce_limit=depth)
+    r.m_RendererSettings = s
+    r.ResizeBuffer(W, H)
+    r.RenderBatch(cam, sc, frames)
+    ref, ref_acc, _ = oracle.render(osc, ocam, o, W, H, 1, frames)
+    return r, ref, ref_acc
+
+
+def test_batch_split_over_several_launches_keeps_sum_order():
+    """A tiny sample-buffer budget forces one launch per frame; the per-pixel sum order must not change."""
+    r, ref, ref_acc = _render_with_env({"DRT_SAMPLE_MB": "1"}, "cornell_box", 320, 200, 5, 4)
+    compare(r.GetRenderTargetImage(), ref, "split batch")
+    compare(r.GetAccumulationBuffer(), ref_acc, "split batch accum")
+
+
+def test_first_kernel_still_matches():
+    """pixel_walk (DRT_KERNEL=pixel_walk), kept for A/B measurements, stays bit-exact too."""
+    r, ref, _ = _render_with_env({"DRT_KERNEL": "pixel_walk"}, "suzanne_plane", 128, 72, 2, 2)
+    assert r.kernelInfo().startswith("pixel_walk")
+    compare(r.GetRenderTargetImage(), ref, "pixel_walk")
+
+
+@pytest.mark.parametrize("votes", [(1, 1, 1, 1), (64, 64, 64, 64), (3, 60, 2, 50)])
+def test_voting_thresholds_do_not_change_the_image(votes):
+    """Scheduling is free (RNG state is a pure function of pixel, frame and draw count): any thresholds, same bits."""
+    env = dict(zip(("DRT_VOTE_N", "DRT_VOTE_S", "DRT_VOTE_R", "DRT_VOTE_P"), map(str, votes)))
+    r, ref, _ = _render_with_env(env, "room", 96, 54, 2, 6)
+    compare(r.GetRenderTargetImage(), ref, "votes %r" % (votes,))
+
+
 def test_exact_rcp_exhaustive():
     """device_math.hpp exact_rcp (used by the triangle test instead of the compiler's 1.0f/x expansion) must equal
     IEEE division for EVERY float: all 2^32 bit patterns are compared on the device."""
