@@ -9,6 +9,9 @@ A "step" is one full progressive render of the frame: reset the accumulation buf
 of the workload (W x H x spp paths: ray generation, BVH traversal, shading, accumulate, resolve) and,
 for N > 1, gather the rank-local framebuffer stripes on rank 0 over RCCL and assemble the image.
 Inputs (scene, BVH, textures) are resident in HBM before the timed region.  One JSON line on rank 0.
+Steps are independent frames; --frames-in-flight (default 3) of them are enqueued at a time, each on its own
+renderer + HIP stream, so the end-of-launch drain of one frame and its gather overlap the next frame's
+ramp-up.  Every step still does all of its work inside the timed region (drained before the closing sync).
 
 Sharding (N > 1): the frame is cut into 8-row stripes dealt round-robin over the ranks
 (drt_renderer_set_shard); RNG seeds use the global pixel index so the image is bit-identical to the
@@ -44,6 +47,11 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cornell_box_1080p_8spp_d8", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="independent frames (steps) kept in flight, each on its own renderer + HIP stream: the drain of one "
+                         "frame overlaps the ramp-up of the next (1 = strictly one after the other)")
+    ap.add_argument("--emulate-shard", default="", help="R/W: render only rank R's stripes of a W-way split on ONE GPU, no gather "
+                    "(what one GPU of a W-GPU run computes; for tuning small-shard behaviour on a 1-GPU box)")
     ap.add_argument("--no-roofline-counters", action="store_true", help="skip the counting launch (roofline = null)")
     return ap.parse_args()
 
@@ -126,38 +134,61 @@ def main():
     cam = drt.Camera(pos)
     cam.m_Forward_dir = np.array(fwd, np.float32)
 
-    r = drt.Renderer(local_rank)
-    r.m_RendererSettings = drt.RendererSettings(ray_bounce_limit=depth, max_samples=spp + 1)
-    r.setShard(STRIPE_ROWS, rank, world)
-    r.ResizeBuffer(W, H)
-    local_rows = r.getLocalRows()
-    padded = max(drt.shard_rows(H, STRIPE_ROWS, k, world) for k in range(world))
-    accum = torch.zeros((padded, W, 3), dtype=torch.float32, device=dev)
-    rgba = torch.zeros((padded, W, 4), dtype=torch.float32, device=dev)
-    r.bindBuffers(accum.data_ptr(), rgba.data_ptr())
-    stream = torch.cuda.current_stream()
-    r.setStream(stream.cuda_stream)
-    gathered = image = None
-    if world > 1 and rank == 0:
-        gathered = torch.empty((world, padded, W, 4), dtype=torch.float32, device=dev)
-        image = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+    shard_rank, shard_world = rank, world
+    if args.emulate_shard and world == 1:
+        shard_rank, shard_world = (int(v) for v in args.emulate_shard.split("/"))
+    padded = max(drt.shard_rows(H, STRIPE_ROWS, k, shard_world) for k in range(shard_world))
 
+    class Slot:
+        """One frame in flight: a renderer with its own HIP stream and buffers."""
+
+        def __init__(self):
+            self.r = drt.Renderer(local_rank)
+            self.r.m_RendererSettings = drt.RendererSettings(ray_bounce_limit=depth, max_samples=spp + 1)
+            self.r.setShard(STRIPE_ROWS, shard_rank, shard_world)
+            self.r.ResizeBuffer(W, H)
+            self.accum = torch.zeros((padded, W, 3), dtype=torch.float32, device=dev)
+            self.rgba = torch.zeros((padded, W, 4), dtype=torch.float32, device=dev)
+            self.r.bindBuffers(self.accum.data_ptr(), self.rgba.data_ptr())
+            self.stream = torch.cuda.Stream(device=dev)
+            self.r.setStream(self.stream.cuda_stream)
+            self.gathered = self.image = self.host = None
+            if world > 1 and rank == 0:
+                self.gathered = torch.empty((world, padded, W, 4), dtype=torch.float32, device=dev)
+                self.image = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+            self.busy = False
+
+    slots = [Slot() for _ in range(max(1, args.frames_in_flight))]
+    r = slots[0].r
     kernel_ms = []
 
-    def step():
-        r.resetAccumulationBuffer()
-        kernel_ms.append(r.RenderBatch(cam, scene, spp))          # blocking; ms from HIP events on the launch stream
-        if world > 1:
-            if rehearsal:
-                host = torch.empty((world,) + tuple(rgba.shape), dtype=torch.float32) if rank == 0 else None
-                gather_shards(rgba.cpu(), host, rank)
+    def retire(slot):
+        if slot.busy:
+            kernel_ms.append(slot.r.Wait())          # device time of that step's launches (HIP events on its stream)
+            slot.busy = False
+
+    def step(i):
+        slot = slots[i % len(slots)]
+        retire(slot)                                  # the step that used this slot before must be done
+        with torch.cuda.stream(slot.stream):
+            slot.r.resetAccumulationBuffer()
+            slot.r.RenderBatchAsync(cam, scene, spp)
+            slot.busy = True
+            if world > 1:
+                if rehearsal:
+                    host = torch.empty((world,) + tuple(slot.rgba.shape), dtype=torch.float32) if rank == 0 else None
+                    gather_shards(slot.rgba.cpu(), host, rank)
+                    if rank == 0:
+                        slot.gathered.copy_(host)
+                else:
+                    gather_shards(slot.rgba, slot.gathered, rank)
                 if rank == 0:
-                    gathered.copy_(host)
-            else:
-                gather_shards(rgba, gathered, rank)
-            if rank == 0:
-                drt.assemble_shards(gathered.data_ptr(), image.data_ptr(), W, H, STRIPE_ROWS, world, padded,
-                                    torch.cuda.current_stream().cuda_stream)
+                    drt.assemble_shards(slot.gathered.data_ptr(), slot.image.data_ptr(), W, H, STRIPE_ROWS, world, padded,
+                                        slot.stream.cuda_stream)
+
+    def drain():
+        for slot in slots:
+            retire(slot)
 
     def sync():
         torch.cuda.synchronize()
@@ -177,22 +208,25 @@ def main():
         alg_bytes = c.algorithmic_bytes()
         r.setCounting(False)
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
+    drain()
     kernel_ms.clear()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
+    drain()
     sync()
     elapsed = time.perf_counter() - t0
+    image = slots[(args.steps - 1) % len(slots)].image
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
-        total_samples = W * H * spp
+        total_samples = W * H * spp if shard_world == world else W * drt.shard_rows(H, STRIPE_ROWS, shard_rank, shard_world) * spp
         ms_per_step = elapsed / args.steps * 1e3
         value = total_samples * args.steps / elapsed / 1e6
         avg_kernel_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
@@ -202,6 +236,10 @@ def main():
             roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(args.workload) if world == 1 else None,
                         "kernel": r.kernelInfo(), "kernel_ms": round(avg_kernel_ms, 4),
+                        "note": ("kernel_ms = HIP-event time of one step's launches on its stream; with %d frames in flight the "
+                                 "launches of different steps share the GPU, so it is longer than the launch alone would take "
+                                 "(use --frames-in-flight 1 for the isolated figure)" % len(slots)) if len(slots) > 1 else "isolated launches",
+                        "achieved_aggregate": round(alg_bytes * args.steps / elapsed / 1e9, 2),
                         "algorithmic_bytes_per_launch": int(alg_bytes),
                         "bytes_per_sample": round(alg_bytes / max(counters["samples"], 1), 1)}
         out = {"metric": "Msamples/sec at 1920x1080, 8spp, cornell_box" if args.workload == "cornell_box_1080p_8spp_d8" else "Msamples/sec",
@@ -210,7 +248,8 @@ def main():
                "dtype": "f32", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on device 0, gloo gather)",
                "config": {"workload": args.workload, "scene": SCENES[scene_key][0], "width": W, "height": H, "spp": spp,
                           "depth": depth, "bvh": "leaf20/bins8", "pose": {"pos": list(pos), "fwd": list(fwd)},
-                          "parallelism": "stripes%dx%d" % (STRIPE_ROWS, world) if world > 1 else "single"},
+                          "parallelism": "stripes%dx%d" % (STRIPE_ROWS, world) if world > 1 else "single",
+                          "frames_in_flight": len(slots)},
                "roofline": roofline}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(scene_key, W, H, depth, args.cpu_seconds)

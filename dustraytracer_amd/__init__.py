@@ -196,6 +196,8 @@ _sig("drt_renderer_set_settings", C.c_int, _P, C.POINTER(RendererSettings))
 _sig("drt_renderer_get_settings", C.c_int, _P, C.POINTER(RendererSettings))
 _sig("drt_renderer_render", C.c_int, _P, C.POINTER(_CameraPOD), _P, C.POINTER(C.c_float))
 _sig("drt_renderer_render_batch", C.c_int, _P, C.POINTER(_CameraPOD), _P, C.c_uint32, C.POINTER(C.c_float))
+_sig("drt_renderer_render_batch_async", C.c_int, _P, C.POINTER(_CameraPOD), _P, C.c_uint32)
+_sig("drt_renderer_wait", C.c_int, _P, C.POINTER(C.c_float))
 _sig("drt_renderer_reset", C.c_int, _P)
 for _n in ("width", "height", "sample_count", "local_rows"):
     _sig("drt_renderer_%s" % _n, C.c_uint32, _P)
@@ -359,6 +361,17 @@ class Renderer:
         ms = C.c_float(0)
         pod = cam._pod()
         _check(_lib.drt_renderer_render_batch(self._h, C.byref(pod), scene._h, n_frames, C.byref(ms)))
+        return ms.value
+
+    def RenderBatchAsync(self, cam, scene, n_frames):
+        """Enqueue only; Wait() blocks and returns the device time in ms."""
+        self._push_settings()
+        pod = cam._pod()
+        _check(_lib.drt_renderer_render_batch_async(self._h, C.byref(pod), scene._h, n_frames))
+
+    def Wait(self):
+        ms = C.c_float(0)
+        _check(_lib.drt_renderer_wait(self._h, C.byref(ms)))
         return ms.value
 
     def resetAccumulationBuffer(self):

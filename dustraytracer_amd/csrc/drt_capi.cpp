@@ -83,6 +83,7 @@ struct drt_renderer {
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool counting = false;
+    bool pending = false;                     // an asynchronous render was enqueued and not waited for yet
     unsigned long long *counters = nullptr;
     unsigned int *tile_counter = nullptr;     // work queue head of the wave_queue kernel
     void *samples = nullptr;                  // wave_queue: one float4 per (pixel, frame) of a launch
@@ -458,10 +459,11 @@ static void fill_frame_params(const drt_renderer *r, const drt_camera *cam, Fram
     fp.vote_node = r->vote_node; fp.vote_shade = r->vote_shade; fp.vote_dir = r->vote_dir; fp.vote_spec = r->vote_spec;
 }
 
-int drt_renderer_render_batch(drt_renderer *r, const drt_camera *cam, const drt_scene *scene, uint32_t n_frames,
-                              float *delta_ms) {
+static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_scene *scene, uint32_t n_frames,
+                             float *delta_ms, bool blocking) {
     if (!r || !cam || !scene) return fail(DRT_ERR_INVALID, "null argument");
     if (delta_ms) *delta_ms = 0.f;
+    r->pending = false;
     if (r->width == 0 || r->height == 0) return fail(DRT_ERR_INVALID, "ResizeBuffer has not been called");
     // Renderer.cu:82: nothing happens once m_FrameIndex == max_samples, so at most max_samples-1 frames accumulate.
     if ((int64_t)r->frame_index == (int64_t)r->settings.max_samples) return DRT_OK;
@@ -501,11 +503,31 @@ int drt_renderer_render_batch(drt_renderer *r, const drt_camera *cam, const drt_
         }
     }
     HIP_TRY(hipEventRecord(r->ev_stop, r->stream));                    // Renderer.cu:105
-    HIP_TRY(hipEventSynchronize(r->ev_stop));                          // blocking, Renderer.cu:106
+    r->frame_index += n_frames;                                        // Renderer.cu:116
+    r->pending = true;
+    if (!blocking) return DRT_OK;
+    return drt_renderer_wait(r, delta_ms);                             // blocking, Renderer.cu:106-108
+}
+
+int drt_renderer_render_batch(drt_renderer *r, const drt_camera *cam, const drt_scene *scene, uint32_t n_frames,
+                              float *delta_ms) {
+    return render_batch_impl(r, cam, scene, n_frames, delta_ms, true);
+}
+
+int drt_renderer_render_batch_async(drt_renderer *r, const drt_camera *cam, const drt_scene *scene, uint32_t n_frames) {
+    return render_batch_impl(r, cam, scene, n_frames, nullptr, false);
+}
+
+int drt_renderer_wait(drt_renderer *r, float *delta_ms) {
+    if (!r) return fail(DRT_ERR_INVALID, "null renderer");
+    if (delta_ms) *delta_ms = 0.f;
+    if (!r->pending) return DRT_OK;
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipEventSynchronize(r->ev_stop));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, r->ev_start, r->ev_stop));
     if (delta_ms) *delta_ms = ms;
-    r->frame_index += n_frames;                                        // Renderer.cu:116
+    r->pending = false;
     return DRT_OK;
 }
 

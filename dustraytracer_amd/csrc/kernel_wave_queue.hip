@@ -532,6 +532,8 @@ hipError_t launch_one(const SceneView &sc, const FrameParams &fp, unsigned int *
     }
     const uint64_t n_chunks = (uint64_t)tiles_x * tiles_y * fp.n_frames;
     if (n_chunks > 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    // (Shrinking the grid for small launches was tried: it shortens fill/drain for contiguous rows but loses on the
+    // interleaved stripes of a multi-GPU shard; frames in flight on separate streams hide the drain better.)
     const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)num_cus * per_cu_cache, (n_chunks + 3) / 4));
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), lds_bytes, stream, sc, fp, chunk_counter, (uint32_t)n_chunks, tiles_x, samples);
     return hipGetLastError();

@@ -153,6 +153,10 @@ int           drt_renderer_render(drt_renderer *r, const drt_camera *cam, const 
  * so the result is bit-identical to n_frames drt_renderer_render calls.  Clamped so that sample_count never passes max_samples. */
 int           drt_renderer_render_batch(drt_renderer *r, const drt_camera *cam, const drt_scene *scene,
                                         uint32_t n_frames, float *delta_ms);
+/* Non-blocking form: enqueues the batch on the renderer's stream and returns; drt_renderer_wait blocks until it is done
+ * and returns its device time.  Lets a caller keep several frames in flight (one renderer + stream per frame). */
+int           drt_renderer_render_batch_async(drt_renderer *r, const drt_camera *cam, const drt_scene *scene, uint32_t n_frames);
+int           drt_renderer_wait(drt_renderer *r, float *delta_ms);
 int           drt_renderer_reset(drt_renderer *r);                            /* resetAccumulationBuffer: zero + sample_count = 1 */
 uint32_t      drt_renderer_width(const drt_renderer *r);                      /* getBufferWidth */
 uint32_t      drt_renderer_height(const drt_renderer *r);                     /* getBufferHeight */
