@@ -19,7 +19,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdrt_hip.so")
+LIB_PATH = os.environ.get("DRT_LIB_OVERRIDE") or os.path.join(_HERE, "libdrt_hip.so")      # override: A/B of builds (tools/ab_libs.py)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError("dustraytracer_amd: %s is missing -- the HIP extension must be built "
