@@ -15,6 +15,10 @@ SCENES = {
     "uv_texture_test": (os.path.join("test", "UVtextureTest.glb"), (0.0, 1.0, 4.0), (0.0, -0.1, -1.0), 3),
     "bvh_split_test": (os.path.join("test", "bvhsplitTest.glb"), (0.0, 2.0, 5.0), (0.0, -0.2, -1.0), 2),
     "multi_material": (os.path.join("test", "multiMaterialMeshTest.glb"), (0.0, 2.0, 5.0), (0.0, -0.2, -1.0), 2),
+    # 16 textured materials, 6 RGBA (palettised PNG + tRNS -> 4 channels): the alpha cut-out scene of the reference's only
+    # published timings (beforeBVHbuildrefactor_col.png: 843x460, 5 bounces)
+    "mc_transparency": (os.path.join("test", "mcTransparencyTest.glb"), (0.0, 3.0, 9.0), (0.0, -0.15, -1.0), 5),
+    "lightweight_rt": (os.path.join("test", "lightweightRTtest.glb"), (0.0, 1.8, 7.5), (0.0, -0.1, -1.0), 3),
 }
 
 

@@ -63,7 +63,8 @@ def renderer():
 @pytest.mark.parametrize("name,W,H,frames", [("cornell_box", 256, 256, 1), ("cornell_box", 160, 90, 3),
                                              ("suzanne_plane", 160, 90, 2), ("dense_monkey", 160, 90, 2),
                                              ("room", 128, 72, 2), ("uv_texture_test", 128, 128, 2),
-                                             ("bvh_split_test", 96, 64, 2), ("multi_material", 96, 64, 2)])
+                                             ("bvh_split_test", 96, 64, 2), ("multi_material", 96, 64, 2),
+                                             ("mc_transparency", 211, 115, 3), ("lightweight_rt", 128, 72, 2)])
 def test_image_matches_oracle(renderer, name, W, H, frames):
     sc, osc = make_pair(name)
     depth = 4 if (name, W) == ("cornell_box", 256) else SCENES[name][3]      # C1 = 256x256 1spp depth 4
@@ -152,6 +153,23 @@ def test_alpha_cutout_changes_the_image(renderer):
     s, o = settings_pair(ray_bounce_limit=3)
     _, _, cnt = oracle.render(osc, ocam, o, 128, 128, 1, 1, want_counters=True)
     assert cnt.anyhit_alpha > 0, "pose does not exercise the alpha path"
+
+
+def test_alpha_cutout_scene_with_sun_shadows(renderer):
+    """mcTransparencyTest: RGBA leaves.  Closest-hit AND shadow traversals must skip texels with alpha < 1
+    (AnyHit.cuh:8-28 from BVHTraversal.cuh:52 and :112); also the general (run-time settings) kernel variant."""
+    sc, osc = make_pair("mc_transparency")
+    cam, ocam = cameras("mc_transparency")
+    for kw in (dict(enableSunlight=1, ray_bounce_limit=3), dict(RenderMode=1, DebugMode=3), dict(RenderMode=1, DebugMode=4)):
+        s, o = settings_pair(**kw)
+        renderer.m_RendererSettings = s
+        renderer.ResizeBuffer(168, 92)
+        renderer.resetAccumulationBuffer()
+        renderer.RenderBatch(cam, sc, 2)
+        assert "general" in renderer.kernelInfo()
+        ref, _, cnt = oracle.render(osc, ocam, o, 168, 92, 1, 2, want_counters=True)
+        assert cnt.anyhit_alpha > 0
+        compare(renderer.GetRenderTargetImage(), ref, "mc_transparency %r" % kw)
 
 
 def test_other_leaf_sizes(renderer):

@@ -160,3 +160,59 @@ def grid():
     best.sort()
     for b in best[:12]:
         print("slots/pixel %.0f  thN %d thS %d thR %d  T lanes %.1f  eff %.2f" % (b[0], b[1], b[2], b[3], b[4], ideal / 64 / npx / b[0]))
+
+
+def simulate_own2(pixels, thresholds=(12, 36, 4), swap_cost=35, lanes=64, k_paths=2):
+    """Each lane owns k_paths paths; in a phase run a lane serves ONE of its paths that is in that phase
+    (register-resident alternative: the inactive path is swapped in with swap_cost extra issue slots per run that swaps)."""
+    progs = [lane_program(p, False) for p in pixels]
+    queue = list(range(len(progs)))
+    cur = [[None] * k_paths for _ in range(lanes)]
+    pos = [[0] * k_paths for _ in range(lanes)]
+    active = [0] * lanes
+
+    def refill(l, k):
+        if queue:
+            cur[l][k] = progs[queue.pop()]; pos[l][k] = 0
+        else:
+            cur[l][k] = None
+
+    for l in range(lanes):
+        for k in range(k_paths):
+            refill(l, k)
+    thN, thS, thR = thresholds
+    total = 0.0
+    execs = {"T": 0, "N": 0, "S": 0, "R": 0}; served = dict(execs)
+    while True:
+        st = []
+        for l in range(lanes):
+            row = []
+            for k in range(k_paths):
+                while cur[l][k] is not None and pos[l][k] >= len(cur[l][k]):
+                    refill(l, k)
+                row.append(None if cur[l][k] is None else cur[l][k][pos[l][k]])
+            st.append(row)
+        cnt = {"T": 0, "N": 0, "S": 0, "R": 0}
+        for row in st:
+            for ph in cnt:
+                if ph in row:
+                    cnt[ph] += 1            # lanes that COULD serve this phase with one of their paths
+        if sum(cnt.values()) == 0:
+            break
+        if cnt["S"] >= thS: ph = "S"
+        elif cnt["R"] >= thR: ph = "R"
+        elif cnt["N"] >= thN: ph = "N"
+        elif cnt["T"] > 0: ph = "T"
+        else: ph = max(("N", "S", "R"), key=lambda k: cnt[k])
+        n = 0; swapped = False
+        for l in range(lanes):
+            row = st[l]
+            if ph not in row:
+                continue
+            k = active[l] if row[active[l]] == ph else row.index(ph)
+            if k != active[l]:
+                swapped = True; active[l] = k
+            pos[l][k] += 1; n += 1
+        total += COST[ph] + (swap_cost if swapped else 0)
+        execs[ph] += 1; served[ph] += n
+    return total, execs, served
