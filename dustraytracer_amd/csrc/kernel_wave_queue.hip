@@ -337,9 +337,14 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
                     tex_uv.x = 0; tex_uv.y = 1;
                     bounce = 0;
                     if (COUNT) c_samples++;
-                    begin_closest();
-                    stage = kTraceDone;
-                    arm_direction();
+                    if (fp.bounce_limit >= 0) {
+                        begin_closest();
+                        stage = kTraceDone;
+                        arm_direction();
+                    } else {
+                        stage = kPathDone;           // RayGen.cuh:88: the loop body never runs, the sample is black (post-processed)
+                        sp = 0; cur = end = 0; spec = 0;
+                    }
                 }
                 // a sample outside the image (partial tile) leaves the lane in kNeedSample: it asks again next time
             }
@@ -580,7 +585,8 @@ hipError_t launch_wave_queue(const SceneView &sc, const FrameParams &fp, int bvh
     if (bvh_depth > 64) return hipErrorInvalidValue;
     const size_t stack_bytes = (size_t)stack * kThreads * sizeof(StackEntry);
     const size_t scene_bytes = wave_queue_scene_lds_bytes(sc);
-    const bool lds_scene = scene_bytes <= kLdsSceneBytes;
+    static const size_t lds_scene_budget = std::getenv("DRT_LDS_SCENE_KB") ? (size_t)std::atoi(std::getenv("DRT_LDS_SCENE_KB")) * 1024 : kLdsSceneBytes;
+    const bool lds_scene = scene_bytes <= lds_scene_budget;
     const size_t lds_bytes = stack_bytes + (lds_scene ? scene_bytes : 0);
     hipError_t e = hipMemsetAsync(chunk_counter, 0, sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;

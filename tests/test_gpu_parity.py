@@ -119,7 +119,7 @@ def test_debug_views(renderer, mode):
 
 @pytest.mark.parametrize("kw", [dict(enableSunlight=1), dict(enableSunlight=1, tone_mapping=0),
                                 dict(gamma_correction=0), dict(tone_mapping=0, gamma_correction=0),
-                                dict(ray_bounce_limit=0), dict(sky_intensity=3.5, sky_color=(0.6, 0.7, 1.0))])
+                                dict(ray_bounce_limit=0), dict(ray_bounce_limit=-1), dict(sky_intensity=3.5, sky_color=(0.6, 0.7, 1.0))])
 def test_settings_variants(renderer, kw):
     for name in ("room", "cornell_box"):
         sc, osc = make_pair(name)
