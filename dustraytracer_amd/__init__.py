@@ -146,10 +146,10 @@ class _TexInfo(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "node_visits", "inner_visits", "tri_tests",
                                            "hits_textured", "hits_flat", "shadow_rays", "inner_visits_shadow",
-                                           "tri_tests_shadow")] + [("phase_execs", C.c_uint64 * 4), ("phase_lanes", C.c_uint64 * 4)]
+                                           "tri_tests_shadow")] + [("phase_execs", C.c_uint64 * 4), ("phase_lanes", C.c_uint64 * 4), ("phase_ticks", C.c_uint64 * 4), ("wave_ticks", C.c_uint64)]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, t in self._fields_ if t is C.c_uint64}
+        return {n: int(getattr(self, n)) for n, t in self._fields_ if t is C.c_uint64 and n != "wave_ticks"}
 
     def phase_stats(self):
         """wave_queue kernel: (executions, mean active lanes) of the T, N, S, R phases."""
@@ -163,6 +163,8 @@ class Counters(C.Structure):
 
 
 def _sig(name, restype, *argtypes):
+    if name.startswith("drt_debug_") and not hasattr(_lib, name):
+        return None                   # older A/B builds (DRT_LIB_OVERRIDE) may lack a debug entry point
     fn = getattr(_lib, name)          # AttributeError here = the library does not export what drt.h declares
     fn.restype = restype
     fn.argtypes = list(argtypes)
@@ -216,6 +218,7 @@ _sig("drt_shard_rows", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint3
 _sig("drt_debug_kat", C.c_int, C.c_int32, C.c_int32, _P, C.c_size_t, _P, C.c_size_t, C.c_uint32, C.POINTER(_CameraPOD), C.c_uint32, C.c_uint32)
 _sig("drt_debug_hash_cycles", C.c_int, C.c_int32, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32))
 _sig("drt_debug_check_rcp", C.c_int, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
+_sig("drt_debug_check_sqrt", C.c_int, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 
 EXPORTED_SYMBOLS = [n for n in dir(_lib) if n.startswith("drt_")]
 
@@ -449,6 +452,13 @@ def debug_check_rcp(device=0):
     """(mismatches, fast-path count) of the kernels' exact_rcp vs IEEE 1.0f/x over all 2^32 floats."""
     bad, fast = C.c_uint64(0), C.c_uint64(0)
     _check(_lib.drt_debug_check_rcp(device, C.byref(bad), C.byref(fast)))
+    return int(bad.value), int(fast.value)
+
+
+def debug_check_sqrt(device=0):
+    """(mismatches, fast-path count) of the kernels' exact_sqrt vs sqrtf over all 2^32 floats."""
+    bad, fast = C.c_uint64(0), C.c_uint64(0)
+    _check(_lib.drt_debug_check_sqrt(device, C.byref(bad), C.byref(fast)))
     return int(bad.value), int(fast.value)
 
 

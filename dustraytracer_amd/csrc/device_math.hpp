@@ -33,8 +33,39 @@ DRT_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }     
 DRT_DEV f3 cross(f3 a, f3 b) {                                                                    // helper_math.cuh:1436
     return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+// ---- exact fast forms of 1/x and sqrt(x) ----
+// hipcc's correctly rounded fp32 division / sqrt expansions cost ~42 / ~53 SIMD cycles per wave instruction on gfx950
+// (tools/microbench/valu_issue.hip) because they wrap the refinement in v_div_scale / v_div_fmas / v_div_fixup (or range
+// scaling and special-case selects) that only matter at the ends of the exponent range.  The two functions below keep the
+// refinement and drop the wrapping inside 2^-100 <= |x| <= 2^100, and fall back to the plain operator outside (0, inf, NaN,
+// tiny, huge).  They are NOT approximations: tests/test_gpu_parity.py compares each with the plain operator for EVERY one of
+// the 2^32 float bit patterns on the device (drt_debug_check_rcp / _sqrt, 0 mismatches required).
+DRT_DEV float exact_rcp(float x) {
+    const float ax = __builtin_fabsf(x);
+    if (!(ax >= 0x1p-100f && ax <= 0x1p100f)) return 1.0f / x;
+    float r = __builtin_amdgcn_rcpf(x);
+    float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = r;                                   // 1 * r
+    float rem = __builtin_fmaf(-x, q, 1.0f);
+    q = __builtin_fmaf(rem, r, q);
+    rem = __builtin_fmaf(-x, q, 1.0f);
+    return __builtin_fmaf(rem, r, q);
+}
+DRT_DEV float exact_sqrt(float x) {
+    if (!(x >= 0x1p-100f && x <= 0x1p100f)) return sqrtf(x);
+    // v_sqrt_f32 is within 1 ulp; pick among s-1ulp, s, s+1ulp with exact FMA residuals (the selection step of the
+    // compiler's own expansion)
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    float y = (r_dn <= 0.0f) ? s_dn : s;
+    y = (r_up > 0.0f) ? s_up : y;
+    return y;
+}
+
 DRT_DEV float length(f3 v) { return sqrtf(dot(v, v)); }                                           // helper_math.cuh:1307
-DRT_DEV f3 normalize(f3 v) { float inv_len = 1.0f / sqrtf(dot(v, v)); return v * inv_len; }       // helper_math.cuh:1325
+DRT_DEV f3 normalize(f3 v) { float inv_len = exact_rcp(exact_sqrt(dot(v, v))); return v * inv_len; }   // helper_math.cuh:1325 (1/sqrtf, exact)
 
 // ---- CudaMath/Random.cu ----
 DRT_DEV uint32_t pcg_hash(uint32_t input) {                                                       // :6-11
@@ -87,7 +118,7 @@ DRT_DEV f2 random_in_unit_disk(uint32_t &seed) {                                
 
 // ---- Core/Ray.cuh:5-24 ----
 struct Ray { f3 orig, dir, inv_dir; };
-DRT_DEV Ray make_ray(f3 o, f3 d) { Ray r; r.orig = o; r.dir = d; r.inv_dir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); return r; }
+DRT_DEV Ray make_ray(f3 o, f3 d) { Ray r; r.orig = o; r.dir = d; r.inv_dir = mk3(exact_rcp(d.x), exact_rcp(d.y), exact_rcp(d.z)); return r; }
 
 // ---- Core/Bounds.cu:18-41 ----
 DRT_DEV float slab_intersect(f3 bmin, f3 bmax, const Ray &ray) {
@@ -124,25 +155,6 @@ DRT_DEV bool tri_intersect(const Ray &ray, f3 v0, f3 e1, f3 e2, float &t_out, f3
     return false;
 }
 
-// 1.0f / x, correctly rounded, for the triangle test.  Same refinement chain as the compiler's IEEE division
-// expansion (v_rcp_f32, one Newton step on the reciprocal, two FMA corrections of the quotient) without the
-// v_div_scale / v_div_fmas / v_div_fixup wrapping that only matters when 1/x under- or overflows.  The triangle
-// test uses the result only when |det| >= 1e-6, where it is bit-identical to 1.0f / x: checked for EVERY float
-// with 2^-100 <= |x| <= 2^100 by tests/test_gpu_parity.py::test_exact_rcp_exhaustive (drt_debug_check_rcp);
-// outside that range (and for 0, inf, NaN) the function falls back to the plain division.
-DRT_DEV float exact_rcp(float x) {
-    const float ax = __builtin_fabsf(x);
-    if (!(ax >= 0x1p-100f && ax <= 0x1p100f)) return 1.0f / x;
-    float r = __builtin_amdgcn_rcpf(x);
-    float e = __builtin_fmaf(-x, r, 1.0f);
-    r = __builtin_fmaf(e, r, r);
-    float q = r;                                   // 1 * r
-    float rem = __builtin_fmaf(-x, q, 1.0f);
-    q = __builtin_fmaf(rem, r, q);
-    rem = __builtin_fmaf(-x, q, 1.0f);
-    return __builtin_fmaf(rem, r, q);
-}
-
 // Same test, straight-line: every quantity is computed, the four rejections are combined at the end.
 // A rejected lane may have divided by a tiny or zero det; its u, v, t are then garbage and never used.
 // NaN behaves as in the branchy form: comparisons with NaN are false, so only `t > eps` rejects it.
@@ -153,10 +165,11 @@ DRT_DEV bool tri_intersect_flat(const Ray &ray, f3 v0, f3 e1, f3 e2, float &t, f
     float inv_det = exact_rcp(det);
     f3 tvec = ray.orig - v0;
     u = inv_det * dot(tvec, pvec);
-    ok = ok & !((u < 0.0f) | (u > 1.0f));
     f3 qvec = cross(tvec, e1);
     v = inv_det * dot(ray.dir, qvec);
-    ok = ok & !((v < 0.0f) | (u + v > 1.0f));
+    // (u < 0 | v < 0) and (u > 1 | u + v > 1) through v_min / v_max, which drop a NaN operand exactly as the two separate
+    // comparisons ignore it (a compare + mask costs ~4 cycles on gfx950, min/max 2)
+    ok = ok & (bool)(!(fminf(u, v) < 0.0f)) & (bool)(!(fmaxf(u, u + v) > 1.0f));
     t = inv_det * dot(e2, qvec);
     ok = ok & (t > DRT_TRIANGLE_EPSILON);
     return ok;
@@ -174,7 +187,7 @@ DRT_DEV f3 uncharted2_filmic(f3 v, float exposure) {                            
     f3 white_scale = mk3(1.0f, 1.0f, 1.0f) / uncharted2_tonemap_partial(mk3(11.2f, 11.2f, 11.2f));
     return curr * white_scale;
 }
-DRT_DEV f3 gamma_correction(f3 c) { return mk3(sqrtf(c.x), sqrtf(c.y), sqrtf(c.z)); }             // :49-52
+DRT_DEV f3 gamma_correction(f3 c) { return mk3(exact_sqrt(c.x), exact_sqrt(c.y), exact_sqrt(c.z)); }   // :49-52
 DRT_DEV f3 sky_model(f3 dir, f3 sky_color) {                                                      // :54-61
     float t = 0.5f * (1 + normalize(dir).y);      // 0.5 * float in double, rounded back: exact, == 0.5f * float
     f3 c = ((1 - t) * mk3(1, 1, 1)) + (t * sky_color);

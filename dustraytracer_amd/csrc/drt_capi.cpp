@@ -553,19 +553,26 @@ int drt_renderer_read_accum(drt_renderer *r, float *dst, size_t dst_floats) {
     return read_back(r, r ? r->cur_accum() : nullptr, 3, dst, dst_floats);
 }
 
-int drt_debug_check_rcp(int32_t device, uint64_t *mismatches, uint64_t *fast_path_count) {
+static int debug_check_exact(int32_t device, int which, uint64_t *mismatches, uint64_t *fast_path_count) {
     if (!mismatches || !fast_path_count) return fail(DRT_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(device));
     unsigned long long *d = nullptr;
     HIP_TRY(hipMalloc((void **)&d, 2 * sizeof(unsigned long long)));
     hipError_t e = hipMemset(d, 0, 2 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = launch_check_rcp(0u, 1ull << 32, d, nullptr);
+    if (e == hipSuccess) e = launch_check_rcp(which, 0u, 1ull << 32, d, nullptr);
     unsigned long long h[2] = { 0, 0 };
     if (e == hipSuccess) e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(DRT_ERR_DEVICE, hipGetErrorString(e));
     *mismatches = h[0]; *fast_path_count = h[1];
     return DRT_OK;
+}
+
+int drt_debug_check_rcp(int32_t device, uint64_t *mismatches, uint64_t *fast_path_count) {
+    return debug_check_exact(device, 0, mismatches, fast_path_count);
+}
+int drt_debug_check_sqrt(int32_t device, uint64_t *mismatches, uint64_t *fast_path_count) {
+    return debug_check_exact(device, 1, mismatches, fast_path_count);
 }
 
 int drt_debug_kat(int32_t device, int32_t which, const void *in, size_t in_bytes, void *out, size_t out_bytes, uint32_t n,

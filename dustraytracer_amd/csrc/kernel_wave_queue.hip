@@ -140,6 +140,18 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
         p.ref1 = r.x; p.ref2 = r.y;
         return p;
     };
+    auto fetch_face_normal = [&](int prim) -> f3 {
+        if (LDS_SCENE) {
+            const uint32_t q = lds_hot + __umul24((uint32_t)prim, 48u) + 36u;
+            return mk3(__uint_as_float(lds_load1(q)), __uint_as_float(lds_load1(q + 4)), __uint_as_float(lds_load1(q + 8)));
+        }
+        return ld3(sc.tri_hot[prim].fn);
+    };
+    // TriCold / MatDev / TexDev stay in HBM (L1-resident in practice): staging them in LDS too was measured -- no gain on
+    // cornell, and it pushed room's footprint from 4 to 3 workgroups per CU (-18 %).
+    auto fetch_cold = [&](int prim) -> TriCold { return sc.tri_cold[prim]; };
+    auto fetch_mat = [&](int index) -> MatDev { return sc.mats[index]; };
+    auto fetch_tex = [&](int index) -> TexDev { return sc.texs[index]; };
     auto fetch_leaf = [&](uint32_t id) -> LeafRange {
         if (LDS_SCENE) { const uint2 v = lds_load2(lds_leaf + id * 8u); LeafRange l; l.start = (int)v.x; l.count = (int)v.y; return l; }
         return sc.leaves[id];
@@ -173,9 +185,13 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
     // wave-uniform sample pool: chunk = (tile, frame), pool_next = next unassigned sample of the chunk
     uint32_t chunk = 0, pool_next = 64;
     bool exhausted = false;
+    // (Reading the queue head one chunk ahead was tried: vector-memory results return in order, so the next texel or
+    // material load waits for the outstanding atomic anyway -- 2 % slower.)
     unsigned long long c_samples = 0, c_rays = 0, c_nodes = 0, c_inner = 0, c_tris = 0, c_htex = 0, c_hflat = 0,
                        c_srays = 0, c_sinner = 0, c_stris = 0;
     unsigned long long d_exec[4] = { 0, 0, 0, 0 }, d_lanes[4] = { 0, 0, 0, 0 };     // phase runs / lanes served
+    unsigned long long d_time[4] = { 0, 0, 0, 0 }, d_t0 = 0;                         // shader-clock ticks spent in each phase (counting build only)
+    const unsigned long long d_kernel_t0 = COUNT ? __builtin_amdgcn_s_memtime() : 0;
 
     auto begin_closest = [&]() {                         // TraceRay.cu:15-20 + BVHTraversal.cuh:22-26
         hit_t = FLT_MAX; hit_prim = -1; heat = 0; shadow = false;
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
         // ================= S: shade, finish paths, deal samples, generate primary rays =================
         const int n_s = __popcll(m_s);
         if (n_s >= vote_shade || (m_t == 0 && m_n == 0 && n_s > 0 && n_s >= __popcll(m_r))) {
-            if (COUNT) { d_exec[2]++; d_lanes[2] += (unsigned long long)n_s; }
+            if (COUNT) { d_exec[2]++; d_lanes[2] += (unsigned long long)n_s; d_t0 = __builtin_amdgcn_s_memtime(); }
             const bool in_s = !(cur < end) && !(sp > 0) && !(stage == kNeedDir && spec != 2) && stage != kFinished;
             // (a) a closest-hit traversal finished: RayGen.cuh:90-134
             if (in_s && stage == kTraceDone) {
@@ -223,16 +239,16 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
                 } else {
                     const f3 uvw = mk3(1.0f - hit_u - hit_v, hit_u, hit_v);                // Intersection.cu:31
                     const f3 position = ray.orig + ray.dir * hit_t;                        // ClosestHit.cuh:13
-                    const f3 face_n = ld3(sc.tri_hot[hit_prim].fn);
+                    const f3 face_n = fetch_face_normal(hit_prim);
                     const f3 normal = (dot(face_n, normalize(ray.dir)) > 0.f) ? (-1.f * face_n) : face_n;
-                    const TriCold cold = sc.tri_cold[hit_prim];                            // :111-118
-                    const MatDev mat = sc.mats[cold.material];
+                    const TriCold cold = fetch_cold(hit_prim);                             // :111-118
+                    const MatDev mat = fetch_mat(cold.material);
                     if (mat.tex < 0) {
                         throughput = throughput * ld3(mat.albedo);
                         if (COUNT) c_hflat++;
                     } else {
                         tex_uv = interp_uv(cold, uvw);
-                        throughput = throughput * tex_get_pixel(sc, sc.texs[mat.tex], tex_uv);
+                        throughput = throughput * tex_get_pixel(sc, fetch_tex(mat.tex), tex_uv);
                         if (COUNT) c_htex++;
                     }
                     bounce_origin = position + (normal * 0.001f);                          // :121
@@ -351,6 +367,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
             m_sp = ballot(sp > 0);
             m_dir = ballot(stage == kNeedDir && spec != 2); m_fin = ballot(stage == kFinished);
             m_pend = ballot(spec == 1);
+            if (COUNT) d_time[2] += __builtin_amdgcn_s_memtime() - d_t0;
         }
 
         // ================= R: one candidate of the bounce direction for every lane that has one pending
@@ -361,7 +378,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
             const int n_block = __popcll(~m_t & ~m_sp & m_dir);
             // run when enough directions are pending, when enough lanes are blocked on theirs, or when nothing else can run
             if (n_pend < fp.vote_spec && n_block < vote_dir && !(n_block > 0 && (m_t | (~m_t & m_sp)) == 0)) break;
-            if (COUNT) { d_exec[3]++; d_lanes[3] += (unsigned long long)n_pend; }
+            if (COUNT) { d_exec[3]++; d_lanes[3] += (unsigned long long)n_pend; d_t0 = __builtin_amdgcn_s_memtime(); }
             if (spec == 1) {
                 f3 p;
                 const bool accepted = random_unit_sphere_try(spec_seed, p);
@@ -369,6 +386,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
             }
             m_pend = ballot(spec == 1);
             m_dir = ballot(stage == kNeedDir && spec != 2);
+            if (COUNT) d_time[3] += __builtin_amdgcn_s_memtime() - d_t0;
         }
         // lanes whose direction just became ready are S lanes now; they are picked up by the next trip's S vote
 
@@ -378,7 +396,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
             const int n_n = __popcll(m_n);
             if (n_n == 0) break;
             if (n_n < vote_node && m_t != 0) break;
-            if (COUNT) { d_exec[1]++; d_lanes[1] += (unsigned long long)n_n; }
+            if (COUNT) { d_exec[1]++; d_lanes[1] += (unsigned long long)n_n; d_t0 = __builtin_amdgcn_s_memtime(); }
             if (!(cur < end) && sp > 0) {
                 --sp;
                 const StackEntry e = stack[sp][tid];
@@ -410,6 +428,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
                 }
             }
             m_t = ballot(cur < end); m_sp = ballot(sp > 0);
+            if (COUNT) d_time[1] += __builtin_amdgcn_s_memtime() - d_t0;
         }
 
         // ================= T: one triangle per lane (Intersection.cu:4-36, BVHTraversal.cuh:46-57 / :105-117) ==========
@@ -418,7 +437,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
             const unsigned long long idle = ~m_t & ~m_sp;
             if (__popcll(~m_t & m_sp) >= vote_node || __popcll(idle & m_dir) >= vote_dir ||
                 __popcll(idle & ~m_dir & ~m_fin) >= vote_shade) break;
-            if (COUNT) { d_exec[0]++; d_lanes[0] += (unsigned long long)__popcll(m_t); }
+            if (COUNT) { d_exec[0]++; d_lanes[0] += (unsigned long long)__popcll(m_t); d_t0 = __builtin_amdgcn_s_memtime(); }
             if (!GENERAL && kTrianglesPerStep == 2) {
                 // lean variant: two consecutive triangles of the leaf per step (both loads in flight together, two
                 // independent dependency chains to interleave); hits are applied in leaf order, so ties resolve as in
@@ -452,6 +471,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
             }
             m_t = ballot(cur < end);
             if (GENERAL) m_sp = ballot(sp > 0);
+            if (COUNT) d_time[0] += __builtin_amdgcn_s_memtime() - d_t0;
         }
     }
 
@@ -461,7 +481,11 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
         atomicAdd(&fp.counters[6], c_hflat); atomicAdd(&fp.counters[7], c_srays); atomicAdd(&fp.counters[8], c_sinner);
         atomicAdd(&fp.counters[9], c_stris);
         if (lane == 0)
-            for (int k = 0; k < 4; k++) { atomicAdd(&fp.counters[10 + k], d_exec[k]); atomicAdd(&fp.counters[14 + k], d_lanes[k]); }
+            for (int k = 0; k < 4; k++) {
+                atomicAdd(&fp.counters[10 + k], d_exec[k]); atomicAdd(&fp.counters[14 + k], d_lanes[k]);
+                atomicAdd(&fp.counters[18 + k], d_time[k]);
+            }
+        if (lane == 0) atomicAdd(&fp.counters[22], __builtin_amdgcn_s_memtime() - d_kernel_t0);
     }
 }
 
@@ -482,12 +506,12 @@ __global__ __launch_bounds__(256) void resolve_kernel(const float4 *samples, flo
 }
 
 // Debug: compares exact_rcp(x) with 1.0f / x for every float bit pattern in [first, first + count).
-__global__ __launch_bounds__(256) void check_rcp_kernel(uint32_t first, unsigned long long count, unsigned long long *mismatches,
+__global__ __launch_bounds__(256) void check_rcp_kernel(int which, uint32_t first, unsigned long long count, unsigned long long *mismatches,
                                                         unsigned long long *fast_path) {
     unsigned long long bad = 0, fast = 0;
     for (unsigned long long k = (unsigned long long)blockIdx.x * 256u + threadIdx.x; k < count; k += (unsigned long long)gridDim.x * 256u) {
         const float x = __uint_as_float(first + (uint32_t)k);
-        const float a = exact_rcp(x), b = 1.0f / x;
+        const float a = which == 0 ? exact_rcp(x) : exact_sqrt(x), b = which == 0 ? 1.0f / x : sqrtf(x);
         const uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
         const bool both_nan = (a != a) && (b != b);
         if (ua != ub && !both_nan) bad++;
@@ -559,8 +583,8 @@ hipError_t launch_stack(const SceneView &sc, const FrameParams &fp, int mode, bo
 
 }  // namespace
 
-hipError_t launch_check_rcp(uint32_t first_bits, unsigned long long count, unsigned long long *d_out2, hipStream_t stream) {
-    hipLaunchKernelGGL(check_rcp_kernel, dim3(4096), dim3(256), 0, stream, first_bits, count, d_out2, d_out2 + 1);
+hipError_t launch_check_rcp(int which, uint32_t first_bits, unsigned long long count, unsigned long long *d_out2, hipStream_t stream) {
+    hipLaunchKernelGGL(check_rcp_kernel, dim3(4096), dim3(256), 0, stream, which, first_bits, count, d_out2, d_out2 + 1);
     return hipGetLastError();
 }
 

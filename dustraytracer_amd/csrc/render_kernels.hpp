@@ -19,8 +19,9 @@ size_t wave_queue_sample_bytes(const FrameParams &frame);
 hipError_t launch_wave_queue(const SceneView &scene, const FrameParams &frame, int bvh_depth, int mode, bool scene_has_alpha,
                              unsigned int *chunk_counter, void *samples, int num_cus, hipStream_t stream, const char **kernel_name);
 
-// debug: d_out2[0] += #floats in [first_bits, first_bits+count) where exact_rcp != 1.0f/x, d_out2[1] += #floats on its fast path
-hipError_t launch_check_rcp(uint32_t first_bits, unsigned long long count, unsigned long long *d_out2, hipStream_t stream);
+// debug: d_out2[0] += #floats in [first_bits, first_bits+count) where exact_rcp != 1.0f/x (which 0) or exact_sqrt != sqrtf (which 1),
+// d_out2[1] += #floats on the fast path
+hipError_t launch_check_rcp(int which, uint32_t first_bits, unsigned long long count, unsigned long long *d_out2, hipStream_t stream);
 
 // debug: all values on pcg_hash cycles of length <= max_len; d_out = [count, (value, length) x cap_pairs]
 hipError_t launch_hash_cycles(uint32_t max_len, uint32_t *d_out, uint32_t cap_pairs, hipStream_t stream);

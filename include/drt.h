@@ -106,6 +106,7 @@ typedef struct drt_counters {
              shadow_rays, inner_visits_shadow, tri_tests_shadow;
     /* wave_queue kernel only: executions of the T / N / S / R phase (per wave) and lanes served by them */
     uint64_t phase_execs[4], phase_lanes[4];
+    uint64_t phase_ticks[4], wave_ticks;   /* counting build: shader-clock ticks per phase / per wave lifetime, summed over waves */
 } drt_counters;
 
 typedef struct drt_scene drt_scene;         /* replaces struct Scene, Core/Scene/Scene.cuh:41-57 */
@@ -185,6 +186,7 @@ int           drt_assemble_shards(const void *gathered, void *image, uint32_t wi
                                   uint32_t stripe_rows, uint32_t world, uint32_t padded_rows, void *hip_stream);
 /* Self-check of the kernels' reciprocal (device_math.hpp exact_rcp) against IEEE 1.0f/x over all 2^32 float bit patterns. */
 int           drt_debug_check_rcp(int32_t device, uint64_t *mismatches, uint64_t *fast_path_count);
+int           drt_debug_check_sqrt(int32_t device, uint64_t *mismatches, uint64_t *fast_path_count);   /* exact_sqrt vs sqrtf */
 /* Device leaf functions on arrays, for known-answer tests against tests/golden/kat_ref.npz.
  * which: 0 unit vec (in u32 seed; out vec3,seed,tries), 1 unit sphere (same), 2 slab (in orig3,dir3,min3,max3; out f32),
  * 3 triangle (in orig3,dir3,v0,v1,v2; out t,U,V,W,hit), 4 camera ray (in u,v,seed; out orig3,dir3,seed; needs cam,width,height),

@@ -327,6 +327,13 @@ def test_exact_rcp_exhaustive():
     assert fast > 3_000_000_000          # the fast path really covers 2^-100 <= |x| <= 2^100 (2 * 200 * 2^23 patterns)
 
 
+def test_exact_sqrt_exhaustive():
+    """device_math.hpp exact_sqrt (normalize, gamma) equals the compiler's correctly rounded sqrtf for every float."""
+    bad, fast = drt.debug_check_sqrt(0)
+    assert bad == 0
+    assert fast > 1_600_000_000          # 2^-100 <= x <= 2^100: 200 * 2^23 bit patterns
+
+
 def test_full_size_properties(renderer):
     """BASELINE config C2 at full size (1920x1080, 8 spp, depth 8): size-independent properties.
     The oracle would take ~1 min here, so the whole frame is checked through invariants and a

@@ -18,6 +18,9 @@ print(r.kernelInfo(), "counting ms %.2f" % ms, c.as_dict())
 ps = c.phase_stats(); print("phase stats", ps)
 tot = sum(e for e, _ in ps.values())
 print("execs (M): " + "  ".join("%s %.2f @ %.1f lanes" % (k, ps[k][0] / 1e6, ps[k][1]) for k in "TNSR"))
+tt = [int(c.phase_ticks[i]) for i in range(4)]; wt = int(c.wave_ticks)
+print("wave time shares: " + "  ".join("%s %.1f%%" % (k, 100.0 * tt[i] / wt) for i, k in enumerate("TNSR")) + "  other %.1f%%" % (100.0 * (wt - sum(tt)) / wt))
+print("ticks per phase run: " + "  ".join("%s %.0f" % (k, tt[i] / max(int(c.phase_execs[i]), 1)) for i, k in enumerate("TNSR")))
 for k in range(3):
     r.resetAccumulationBuffer(); ms = r.RenderBatch(cam, sc, spp)
 print(r.kernelInfo(), "ms %.3f  %.1f Msamples/s" % (ms, W * H * spp / ms / 1e3))
