@@ -50,6 +50,7 @@ typedef struct { float x, y; } f2;
 static unsigned char *g_trace = NULL;
 static size_t g_trace_len = 0, g_trace_cap = 0;
 static inline void trace(unsigned char c) { if (g_trace && g_trace_len < g_trace_cap) g_trace[g_trace_len++] = c; }
+static int g_trace_passed_u = 0;      /* last tri_intersect got past the u test ('T' in the trace, else 't') */
 
 /* ---- helper_math.cuh subset (each op rounds once; no contraction) ---- */
 static inline f3 v3(float x, float y, float z) { f3 r = { x, y, z }; return r; }
@@ -168,6 +169,7 @@ static inline short_hit tri_intersect(const ray_t *ray, const float p[3][3])
     float u = inv_det * dot3(tvec, pvec);
     if (u < 0.0f || u > 1.0f)
         return out;
+    g_trace_passed_u = 1;
     f3 qvec = cross3(tvec, v0v1);
     float v = inv_det * dot3(ray->dir, qvec);
     if (v < 0.0f || u + v > 1.0f)
@@ -263,8 +265,9 @@ static void traverse_bvh(const ray_t *ray, int root, hit_payload *closest, const
         if (node->is_leaf) {
             for (int i = node->prim_start; i < node->prim_start + node->prim_count; i++) {
                 const o_triangle *tri = &sc->tris[i];
+                g_trace_passed_u = 0;
                 short_hit h = tri_intersect(ray, tri->p);
-                trace('T');
+                trace(g_trace_passed_u ? 'T' : 't');
                 if (cnt) cnt->tri_tests++;
                 if (h.hit && h.t < closest->t) {                                         /* :51 */
                     if (!any_hit(sc, tri, h.uvw, cnt)) continue;

@@ -216,3 +216,30 @@ def simulate_own2(pixels, thresholds=(12, 36, 4), swap_cost=35, lanes=64, k_path
         total += COST[ph] + (swap_cost if swapped else 0)
         execs[ph] += 1; served[ph] += n
     return total, execs, served
+
+
+def simulate_policy(pixels, choose, lanes=64):
+    """Generic policy: choose(cnt) -> phase letter given counts of lanes per class."""
+    progs = [lane_program(p, False) for p in pixels]
+    queue = list(range(len(progs)))
+    cur = [None] * lanes; pos = [0] * lanes
+    def refill(i):
+        if queue: cur[i] = progs[queue.pop()]; pos[i] = 0
+        else: cur[i] = None
+    for i in range(lanes): refill(i)
+    total = 0.0; execs = {"T": 0, "N": 0, "S": 0, "R": 0}; served = dict(execs)
+    while True:
+        state = []
+        for i in range(lanes):
+            while cur[i] is not None and pos[i] >= len(cur[i]): refill(i)
+            state.append(None if cur[i] is None else cur[i][pos[i]])
+        cnt = {"T": 0, "N": 0, "S": 0, "R": 0}
+        for s_ in state:
+            if s_ is not None: cnt[s_] += 1
+        if sum(cnt.values()) == 0: break
+        ph = choose(cnt)
+        n = 0
+        for i in range(lanes):
+            if state[i] == ph: pos[i] += 1; n += 1
+        total += COST[ph]; execs[ph] += 1; served[ph] += n
+    return total, execs, served
