@@ -35,6 +35,9 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cycles,
                 if (KIND == 10) a[i] = __builtin_sqrtf(a[i] * 1.01f);                   // v_mul + IEEE sqrt expansion
                 if (KIND == 11) a[i] = 1.0f / (a[i] * 1.01f);                           // v_mul + IEEE div expansion
                 if (KIND == 12) a[i] = (float)u[i] * 0x1p-31f - a[i];                   // v_cvt_f32_u32 + v_mul + v_sub (3 ops) 
+                if (KIND == 15) { if (i == 0) a[0] = __builtin_fmaf(a[0], 1.0001f, 0.5f); }                // ONE dependent chain
+                if (KIND == 16) { if (i < 4) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f); }                  // four chains
+                if (KIND == 17) { if (i < 2) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f); }                  // two chains
                 if (KIND == 13) { bool c = a[i] < s; m ^= __builtin_amdgcn_ballot_w64(c); }   // v_cmp to SGPR + s_xor
                 if (KIND == 14) a[i] = (msk >> ((i + r) & 63) & 1) ? a[i] * 1.0001f : a[i];     // scalar-mask select
             }
@@ -82,5 +85,7 @@ int main() {
     run<4>("v_rcp_f32", 1); run<5>("v_mul_lo_u32 + v_add", 2); run<6>("v_lshrrev + v_add + v_xor", 3); run<7>("v_cmp + v_mul + v_cndmask", 3);
     run<8>("v_mul + v_min", 2); run<9>("v_mad_u32_u24", 1); run<10>("v_mul + IEEE sqrtf (instr count?)", 1); run<11>("v_mul + IEEE 1/x", 1);
     run<12>("v_cvt_f32_u32 + v_mul + v_sub", 3); run<13>("v_cmp->SGPR (+s_xor)", 1);
+    printf("dependent chains (rate counts only the chain ops: 1/16, 4/16, 2/16 of the slots):\n");
+    run<15>("1 dependent v_fma chain (x16)", 1); run<17>("2 chains (x8)", 1); run<16>("4 chains (x4)", 1);
     return 0;
 }
