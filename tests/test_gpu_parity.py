@@ -359,3 +359,26 @@ def test_full_size_properties(renderer):
     ref, _, _ = oracle.render(osc, ocam, o, W, H, 1, spp, stripe_rows=8, rank=3, world=16)
     rows = np.array([y for y in range(H) if (y // 8) % 16 == 3])
     compare(img[rows], ref[rows], "C2 band")
+
+
+@pytest.mark.parametrize("name,W,H,spp,depth,stripe_world", [("suzanne_plane", 1920, 1080, 8, 2, 16),        # BASELINE configs[2]
+                                                            ("dense_monkey", 1920, 1080, 16, 2, 16),       # configs[3]
+                                                            ("room", 3840, 2160, 64, 16, 270)])            # configs[4]
+def test_other_baseline_configs_at_full_size(renderer, name, W, H, spp, depth, stripe_world):
+    """Full-size BASELINE configs: frame-wide invariants plus one band of 8-row stripes against the oracle."""
+    sc, osc = make_pair(name)
+    cam, ocam = cameras(name)
+    s, o = settings_pair(ray_bounce_limit=depth, max_samples=spp + 1)
+    renderer.m_RendererSettings = s
+    renderer.ResizeBuffer(W, H)
+    renderer.resetAccumulationBuffer()
+    renderer.RenderBatch(cam, sc, spp)
+    assert renderer.getSampleCount() == spp + 1
+    img = renderer.GetRenderTargetImage()
+    acc = renderer.GetAccumulationBuffer()
+    assert np.isfinite(img).all() and (img[..., 3] == 1).all()
+    assert img[..., :3].min() >= 0 and img[..., :3].max() < 1.25
+    assert np.array_equal(bits(img[..., :3]), bits(acc / np.float32(spp)))
+    ref, _, _ = oracle.render(osc, ocam, o, W, H, 1, spp, stripe_rows=8, rank=stripe_world // 2, world=stripe_world)
+    rows = np.array([y for y in range(H) if (y // 8) % stripe_world == stripe_world // 2])
+    compare(img[rows], ref[rows], "%s full size band" % name)
