@@ -382,3 +382,27 @@ def test_other_baseline_configs_at_full_size(renderer, name, W, H, spp, depth, s
     ref, _, _ = oracle.render(osc, ocam, o, W, H, 1, spp, stripe_rows=8, rank=stripe_world // 2, world=stripe_world)
     rows = np.array([y for y in range(H) if (y // 8) % stripe_world == stripe_world // 2])
     compare(img[rows], ref[rows], "%s full size band" % name)
+
+
+def test_headless_cli_example_writes_the_image(tmp_path):
+    """examples/drt_render.cpp (C++ wrapper classes over the C ABI): scene.glb -> PNG, as the editor's "save png" would."""
+    import os
+    import subprocess
+    from PIL import Image
+    from tests.scenes import ROOT
+    exe = tmp_path / "drt_render"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "drt_render.cpp"),
+                    "-L" + os.path.join(ROOT, "dustraytracer_amd"), "-ldrt_hip", "-Wl,-rpath," + os.path.join(ROOT, "dustraytracer_amd"),
+                    "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    out = tmp_path / "cornell.png"
+    name = "cornell_box"
+    _, pos, fwd, _ = SCENES[name]
+    args = [str(exe), scene_path(name), str(out), "96", "64", "2", "4"] + [str(v) for v in pos] + [str(v) for v in fwd]
+    r = subprocess.run(args, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    png = np.asarray(Image.open(out))
+    assert png.shape == (64, 96, 4)
+    osc = oracle.Scene.load_glb(scene_path(name)).build_bvh(20, 8)
+    ref, _, _ = oracle.render(osc, oracle.default_camera(position=pos, forward=fwd), oracle.default_settings(ray_bounce_limit=4), 96, 64, 1, 2)
+    want = (np.clip(ref[::-1], 0, 1) * np.float32(255) + np.float32(0.5)).astype(np.uint8)
+    assert np.array_equal(png, want)
