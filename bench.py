@@ -37,6 +37,7 @@ WORKLOADS = {
     "suzanne_plane_1080p_8spp_d2": ("suzanne_plane", 1920, 1080, 8, 2),      # configs[2]
     "dense_monkey_1080p_16spp_d2": ("dense_monkey", 1920, 1080, 16, 2),      # configs[3]
     "room_4k_64spp_d16": ("room", 3840, 2160, 64, 16),                       # configs[4]
+    "cs16_dust_1080p_8spp_d5": ("cs16_dust", 1920, 1080, 8, 5),              # large closed map: scene served from L2/HBM, not LDS
 }
 
 
@@ -56,13 +57,27 @@ def parse_args():
     return ap.parse_args()
 
 
+def usable_cores():
+    """Threads worth starting: the affinity mask, capped by the cgroup CPU quota (a 256-thread host that grants this
+    container 16 cores' worth of time only gets slower with 256 runnable threads)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(scene_key, W, H, depth, target_seconds):
     """The oracle (oracle/drt_oracle.c, our CPU restatement = kind "port") timed on this host's cores on a
     bounded sample of the same workload: full-width stripes of the same frame, frame index 1.."""
     import oracle
     from tests.scenes import SCENES, scene_path
     _, pos, fwd, _ = SCENES[scene_key]
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     osc = oracle.Scene.load_glb(scene_path(scene_key)).build_bvh(20, 8)
     cam = oracle.default_camera(position=pos, forward=fwd)
     st = oracle.default_settings(ray_bounce_limit=depth)

@@ -50,7 +50,7 @@ typedef struct { float x, y; } f2;
 static unsigned char *g_trace = NULL;
 static size_t g_trace_len = 0, g_trace_cap = 0;
 static inline void trace(unsigned char c) { if (g_trace && g_trace_len < g_trace_cap) g_trace[g_trace_len++] = c; }
-static int g_trace_passed_u = 0;      /* last tri_intersect got past the u test ('T' in the trace, else 't') */
+static __thread int g_trace_passed_u = 0;      /* last tri_intersect got past the u test ('T' in the trace, else 't') */
 
 /* ---- helper_math.cuh subset (each op rounds once; no contraction) ---- */
 static inline f3 v3(float x, float y, float z) { f3 r = { x, y, z }; return r; }

@@ -18,6 +18,9 @@ SCENES = {
     # 16 textured materials, 6 RGBA (palettised PNG + tRNS -> 4 channels): the alpha cut-out scene of the reference's only
     # published timings (beforeBVHbuildrefactor_col.png: 843x460, 5 bounces)
     "mc_transparency": (os.path.join("test", "mcTransparencyTest.glb"), (0.0, 3.0, 9.0), (0.0, -0.15, -1.0), 5),
+    # a full Counter-Strike map from the reference's models/source (11 167 triangles, 23 textured materials, closed
+    # geometry: every path runs to the bounce limit): the large-scene case whose BVH and triangles do not fit in LDS
+    "cs16_dust": ("cs16_dust.glb", (-11.4, 1.5, -3.85), (0.0, 0.0, 1.0), 5),
     "lightweight_rt": (os.path.join("test", "lightweightRTtest.glb"), (0.0, 1.8, 7.5), (0.0, -0.1, -1.0), 3),
 }
 
