@@ -94,6 +94,7 @@ struct drt_renderer {
     bool scene_has_alpha = false;
     int vote_node = 12, vote_shade = 36, vote_dir = 4, vote_spec = 8;   // wave_queue phase-voting thresholds (DRT_VOTE_N/S/R/P override)
     const char *kernel_name = "";
+    int launch_shape[3] = { 0, 0, 0 };       // wave_queue: stack slots per lane, workgroups per CU, LDS KiB per workgroup
     // device copy of the scene last rendered
     const drt_scene *uploaded_scene = nullptr;
     uint64_t uploaded_revision = 0;
@@ -387,7 +388,10 @@ int drt_renderer_get_counters(drt_renderer *r, drt_counters *out) {
 
 int drt_renderer_kernel_info(const drt_renderer *r, char *buf, size_t cap) {
     if (!r || !buf || cap == 0) return fail(DRT_ERR_INVALID, "bad argument");
-    std::snprintf(buf, cap, "%s", r->kernel_name);
+    if (r->launch_shape[1] > 0 && std::strncmp(r->kernel_name, "wave_queue", 10) == 0)
+        std::snprintf(buf, cap, "%s stack=%d wg/CU=%d lds=%dKiB", r->kernel_name, r->launch_shape[0], r->launch_shape[1], r->launch_shape[2]);
+    else
+        std::snprintf(buf, cap, "%s", r->kernel_name);
     return DRT_OK;
 }
 
@@ -499,7 +503,7 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
             fp.frame_first = r->frame_index + done;
             fp.n_frames = std::min(frames_per_launch, n_frames - done);
             HIP_TRY(launch_wave_queue(r->view, fp, r->bvh_depth, r->counting ? 2 : 0, r->scene_has_alpha, r->tile_counter,
-                                      r->samples, r->num_cus, r->stream, &r->kernel_name));
+                                      r->samples, r->num_cus, r->stream, &r->kernel_name, r->launch_shape));
         }
     }
     HIP_TRY(hipEventRecord(r->ev_stop, r->stream));                    // Renderer.cu:105

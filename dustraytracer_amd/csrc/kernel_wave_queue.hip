@@ -81,10 +81,11 @@ DRT_DEV int lane_rank(unsigned long long mask) {        // set bits below this l
 
 // MODE 0: lean (NORMALMODE, tonemap+gamma on, no sunlight, no RGBA texture, no counters); 1: every setting honoured
 // at run time; 2: = 1 + exact work counters
-template <int STACK, int MODE, bool LDS_SCENE>
+// stack_entries = traversal stack slots per lane (the BVH's depth): the LDS a workgroup takes is exactly what its tree needs
+template <int MODE, bool LDS_SCENE>
 __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc, const FrameParams fp,
                                                               unsigned int *chunk_counter, uint32_t n_chunks, uint32_t tiles_x,
-                                                              float4 *samples) {
+                                                              float4 *samples, uint32_t stack_entries) {
     constexpr bool GENERAL = MODE >= 1;
     constexpr bool COUNT = MODE == 2;
     extern __shared__ uint4 lds_raw[];
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
     const int lane = tid & 63;
 
     // ---- scene source: LDS copy (indexed in uint4 units from lds_raw) or HBM ----
-    constexpr uint32_t kSceneBase = (uint32_t)STACK * kThreads * sizeof(StackEntry) / 16;
+    const uint32_t kSceneBase = stack_entries * (uint32_t)(kThreads * sizeof(StackEntry) / 16);
     const uint32_t hot_base = kSceneBase + sc.n_inner * 4u;
     const uint32_t leaf_base = hot_base + sc.n_tris * 3u;
     if (LDS_SCENE) {
@@ -174,7 +175,11 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
     int hit_prim = -1;
     float heat = 0;
     f3 light = mk3(0, 0, 0), throughput = mk3(1, 1, 1);
-    f3 bounce_origin = mk3(0, 0, 0), bounce_normal = mk3(0, 0, 0);      // kept across a shadow traversal / R tries
+    // Origin and normal of the next bounce, kept from the shaded hit until its direction is drawn.  Only a sun shadow
+    // traversal (GENERAL) still needs the ray in between, so the lean kernel keeps them in the dead ray's registers.
+    f3 bounce_origin_own = mk3(0, 0, 0), bounce_normal_own = mk3(0, 0, 0);
+    f3 &bounce_origin = GENERAL ? bounce_origin_own : ray.orig;
+    f3 &bounce_normal = GENERAL ? bounce_normal_own : ray.dir;
     f2 tex_uv; tex_uv.x = 0; tex_uv.y = 1;
     uint32_t seed = 0, slot = 0;     // slot: where this sample's colour goes in `samples`
     int bounce = 0;
@@ -539,11 +544,11 @@ __global__ __launch_bounds__(256) void hash_cycles_kernel(uint32_t max_len, uint
     }
 }
 
-template <int STACK, int MODE, bool LDS_SCENE>
+template <int MODE, bool LDS_SCENE>
 hipError_t launch_one(const SceneView &sc, const FrameParams &fp, unsigned int *chunk_counter, float4 *samples,
-                      size_t lds_bytes, int num_cus, hipStream_t stream) {
+                      uint32_t stack_entries, size_t lds_bytes, int num_cus, hipStream_t stream, int *blocks_per_cu) {
     const uint32_t tiles_x = (fp.width + 7) / 8, tiles_y = (fp.local_rows + 7) / 8;
-    auto kernel = wave_queue_kernel<STACK, MODE, LDS_SCENE>;
+    auto kernel = wave_queue_kernel<MODE, LDS_SCENE>;
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
@@ -559,26 +564,26 @@ hipError_t launch_one(const SceneView &sc, const FrameParams &fp, unsigned int *
         if (const char *cap = std::getenv("DRT_MAX_BLOCKS_PER_CU")) per_cu_cache = std::max(1, std::min(per_cu_cache, std::atoi(cap)));
         per_cu_lds = lds_bytes;
     }
+    if (blocks_per_cu) *blocks_per_cu = per_cu_cache;
     const uint64_t n_chunks = (uint64_t)tiles_x * tiles_y * fp.n_frames;
     if (n_chunks > 0xFFFFFFF0ull) return hipErrorInvalidValue;
     // (Shrinking the grid for small launches was tried: it shortens fill/drain for contiguous rows but loses on the
     // interleaved stripes of a multi-GPU shard; frames in flight on separate streams hide the drain better.)
     const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)num_cus * per_cu_cache, (n_chunks + 3) / 4));
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), lds_bytes, stream, sc, fp, chunk_counter, (uint32_t)n_chunks, tiles_x, samples);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), lds_bytes, stream, sc, fp, chunk_counter, (uint32_t)n_chunks, tiles_x, samples, stack_entries);
     return hipGetLastError();
 }
 
-template <int STACK>
-hipError_t launch_stack(const SceneView &sc, const FrameParams &fp, int mode, bool lds_scene, unsigned int *chunk_counter,
-                        float4 *samples, size_t lds_bytes, int num_cus, hipStream_t stream) {
+hipError_t launch_mode(const SceneView &sc, const FrameParams &fp, int mode, bool lds_scene, unsigned int *chunk_counter,
+                       float4 *samples, uint32_t stack_entries, size_t lds_bytes, int num_cus, hipStream_t stream, int *blocks_per_cu) {
     if (lds_scene) {
-        if (mode == 0) return launch_one<STACK, 0, true>(sc, fp, chunk_counter, samples, lds_bytes, num_cus, stream);
-        if (mode == 1) return launch_one<STACK, 1, true>(sc, fp, chunk_counter, samples, lds_bytes, num_cus, stream);
-        return launch_one<STACK, 2, true>(sc, fp, chunk_counter, samples, lds_bytes, num_cus, stream);
+        if (mode == 0) return launch_one<0, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
+        if (mode == 1) return launch_one<1, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
+        return launch_one<2, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
     }
-    if (mode == 0) return launch_one<STACK, 0, false>(sc, fp, chunk_counter, samples, lds_bytes, num_cus, stream);
-    if (mode == 1) return launch_one<STACK, 1, false>(sc, fp, chunk_counter, samples, lds_bytes, num_cus, stream);
-    return launch_one<STACK, 2, false>(sc, fp, chunk_counter, samples, lds_bytes, num_cus, stream);
+    if (mode == 0) return launch_one<0, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
+    if (mode == 1) return launch_one<1, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
+    return launch_one<2, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
 }
 
 }  // namespace
@@ -602,11 +607,14 @@ size_t wave_queue_sample_bytes(const FrameParams &fp) {
 }
 
 hipError_t launch_wave_queue(const SceneView &sc, const FrameParams &fp, int bvh_depth, int mode, bool scene_has_alpha,
-                             unsigned int *chunk_counter, void *samples, int num_cus, hipStream_t stream, const char **kernel_name) {
+                             unsigned int *chunk_counter, void *samples, int num_cus, hipStream_t stream, const char **kernel_name,
+                             int *launch_shape) {
     if (fp.width == 0 || fp.local_rows == 0 || fp.n_frames == 0) return hipSuccess;
     if (mode == 0 && (scene_has_alpha || fp.render_mode != 0 || fp.enable_sunlight || !fp.tone_mapping || !fp.gamma_correction)) mode = 1;
-    const int stack = bvh_depth <= 8 ? 8 : bvh_depth <= 16 ? 16 : bvh_depth <= 32 ? 32 : 64;
+    // one slot per BVH level is all a depth-first walk that pushes both children can ever hold (BVHTraversal.cuh:20
+    // fixes it at 64, which is also the reference's limit)
     if (bvh_depth > 64) return hipErrorInvalidValue;
+    const int stack = std::max(bvh_depth, 1);
     const size_t stack_bytes = (size_t)stack * kThreads * sizeof(StackEntry);
     const size_t scene_bytes = wave_queue_scene_lds_bytes(sc);
     static const size_t lds_scene_budget = std::getenv("DRT_LDS_SCENE_KB") ? (size_t)std::atoi(std::getenv("DRT_LDS_SCENE_KB")) * 1024 : kLdsSceneBytes;
@@ -618,13 +626,10 @@ hipError_t launch_wave_queue(const SceneView &sc, const FrameParams &fp, int bvh
                                        { "wave_queue<lean,lds-scene>", "wave_queue<general,lds-scene>", "wave_queue<counting,lds-scene>" } };
     if (kernel_name) *kernel_name = names[lds_scene ? 1 : 0][mode];
     float4 *s4 = static_cast<float4 *>(samples);
-    switch (stack) {
-    case 8: e = launch_stack<8>(sc, fp, mode, lds_scene, chunk_counter, s4, lds_bytes, num_cus, stream); break;
-    case 16: e = launch_stack<16>(sc, fp, mode, lds_scene, chunk_counter, s4, lds_bytes, num_cus, stream); break;
-    case 32: e = launch_stack<32>(sc, fp, mode, lds_scene, chunk_counter, s4, lds_bytes, num_cus, stream); break;
-    default: e = launch_stack<64>(sc, fp, mode, lds_scene, chunk_counter, s4, lds_bytes, num_cus, stream); break;
-    }
+    int blocks_per_cu = 0;
+    e = launch_mode(sc, fp, mode, lds_scene, chunk_counter, s4, (uint32_t)stack, lds_bytes, num_cus, stream, &blocks_per_cu);
     if (e != hipSuccess) return e;
+    if (launch_shape) { launch_shape[0] = stack; launch_shape[1] = blocks_per_cu; launch_shape[2] = (int)(lds_bytes / 1024); }
     const uint32_t local_pixels = fp.width * fp.local_rows;
     hipLaunchKernelGGL(resolve_kernel, dim3((local_pixels + 255) / 256), dim3(256), 0, stream, s4, fp.accum,
                        reinterpret_cast<float4 *>(fp.rgba), local_pixels, fp.n_frames, fp.frame_first + fp.n_frames - 1);
