@@ -82,8 +82,13 @@ DRT_DEV int lane_rank(unsigned long long mask) {        // set bits below this l
 // MODE 0: lean (NORMALMODE, tonemap+gamma on, no sunlight, no RGBA texture, no counters); 1: every setting honoured
 // at run time; 2: = 1 + exact work counters
 // stack_entries = traversal stack slots per lane (the BVH's depth): the LDS a workgroup takes is exactly what its tree needs
+#ifdef DRT_WAVES_PER_EU      // experiments only: force the register budget of that many waves per SIMD
+#define DRT_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(DRT_WAVES_PER_EU, DRT_WAVES_PER_EU)))
+#else
+#define DRT_OCCUPANCY_ATTR
+#endif
 template <int MODE, bool LDS_SCENE>
-__global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc, const FrameParams fp,
+__global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel(const SceneView sc, const FrameParams fp,
                                                               unsigned int *chunk_counter, uint32_t n_chunks, uint32_t tiles_x,
                                                               float4 *samples, uint32_t stack_entries) {
     constexpr bool GENERAL = MODE >= 1;
@@ -183,8 +188,9 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
     f2 tex_uv; tex_uv.x = 0; tex_uv.y = 1;
     uint32_t seed = 0, slot = 0;     // slot: where this sample's colour goes in `samples`
     int bounce = 0;
-    int tries = 0;                   // candidates drawn for the current bounce direction (RNG cycle guard, device_math.hpp)
-    int spec = 0;                    // bounce direction: 0 not requested, 1 pending (R steps work on it), 2 ready
+    // bounce direction: 0 not requested, < 0 ready, > 0 pending (R steps work on it) = 1 + candidates drawn so far
+    // (the count feeds the RNG cycle guard, device_math.hpp)
+    int spec = 0;
     uint32_t spec_seed = 0;          // RNG state of the direction's draws (becomes `seed` when the direction is used)
     f3 spec_p = mk3(0, 0, 0);
     // wave-uniform sample pool: chunk = (tile, frame), pool_next = next unassigned sample of the chunk
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
     // After launching the ray of bounce index `bounce`: its hit will need a direction drawn from seed + bounce
     // (RayGen.cuh:91 then :134), unless sunlight draws come first (then the direction is requested at the hit).
     auto arm_direction = [&]() {
-        if (!debug && !sun && bounce < fp.bounce_limit) { spec = 1; spec_seed = seed + (uint32_t)bounce; tries = 0; }
+        if (!debug && !sun && bounce < fp.bounce_limit) { spec = 1; spec_seed = seed + (uint32_t)bounce; }
         else spec = 0;
     };
 
@@ -222,8 +228,8 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
         // class masks (scalar): a lane is T if it has triangles, else N if it has stack entries, else R / S by stage
         unsigned long long m_t = ballot(cur < end), m_sp = ballot(sp > 0);
         // m_dir: lanes BLOCKED on their bounce direction (hit shaded, direction not ready yet); m_pend: direction pending
-        unsigned long long m_dir = ballot(stage == kNeedDir && spec != 2), m_fin = ballot(stage == kFinished);
-        unsigned long long m_pend = ballot(spec == 1);
+        unsigned long long m_dir = ballot(stage == kNeedDir && spec >= 0), m_fin = ballot(stage == kFinished);
+        unsigned long long m_pend = ballot(spec > 0);
         unsigned long long m_n = ~m_t & m_sp, m_idle = ~m_t & ~m_sp;
         unsigned long long m_r = m_idle & m_dir, m_s = m_idle & ~m_dir & ~m_fin;
         if ((m_t | m_n | m_r | m_s) == 0) break;
@@ -232,7 +238,10 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
         const int n_s = __popcll(m_s);
         if (n_s >= vote_shade || (m_t == 0 && m_n == 0 && n_s > 0 && n_s >= __popcll(m_r))) {
             if (COUNT) { d_exec[2]++; d_lanes[2] += (unsigned long long)n_s; d_t0 = __builtin_amdgcn_s_memtime(); }
-            const bool in_s = !(cur < end) && !(sp > 0) && !(stage == kNeedDir && spec != 2) && stage != kFinished;
+            const bool in_s = !(cur < end) && !(sp > 0) && !(stage == kNeedDir && spec >= 0) && stage != kFinished;
+            // Lean paths gather light only where they end (the sky term below), in the S run that also stores the
+            // sample: the running sum is zero on entry, and resetting it here frees its registers between S runs.
+            if (!GENERAL) light = mk3(0, 0, 0);
             // (a) a closest-hit traversal finished: RayGen.cuh:90-134
             if (in_s && stage == kTraceDone) {
                 seed += (uint32_t)bounce;                                                  // :91
@@ -292,14 +301,14 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
                 // candidate per R step; after the last bounce the reference still draws one, which nothing reads.
                 if (bounce <= fp.bounce_limit) {
                     stage = kNeedDir;
-                    if (spec == 0) { spec = 1; spec_seed = seed; tries = 0; }              // not drawn in the background: request it now
+                    if (spec == 0) { spec = 1; spec_seed = seed; }              // not drawn in the background: request it now
                 } else {
                     stage = kPathDone;
                     spec = 0;
                 }
             }
             // (b2) direction ready: launch the bounce ray  RayGen.cuh:133-134
-            if (in_s && stage == kNeedDir && spec == 2) {
+            if (in_s && stage == kNeedDir && spec < 0) {
                 seed = spec_seed;
                 ray = make_ray(bounce_origin, bounce_normal + spec_p);
                 begin_closest();
@@ -370,8 +379,8 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
                 // a sample outside the image (partial tile) leaves the lane in kNeedSample: it asks again next time
             }
             m_sp = ballot(sp > 0);
-            m_dir = ballot(stage == kNeedDir && spec != 2); m_fin = ballot(stage == kFinished);
-            m_pend = ballot(spec == 1);
+            m_dir = ballot(stage == kNeedDir && spec >= 0); m_fin = ballot(stage == kFinished);
+            m_pend = ballot(spec > 0);
             if (COUNT) d_time[2] += __builtin_amdgcn_s_memtime() - d_t0;
         }
 
@@ -384,13 +393,13 @@ __global__ __launch_bounds__(kThreads) void wave_queue_kernel(const SceneView sc
             // run when enough directions are pending, when enough lanes are blocked on theirs, or when nothing else can run
             if (n_pend < fp.vote_spec && n_block < vote_dir && !(n_block > 0 && (m_t | (~m_t & m_sp)) == 0)) break;
             if (COUNT) { d_exec[3]++; d_lanes[3] += (unsigned long long)n_pend; d_t0 = __builtin_amdgcn_s_memtime(); }
-            if (spec == 1) {
+            if (spec > 0) {
                 f3 p;
                 const bool accepted = random_unit_sphere_try(spec_seed, p);
-                if (accepted || ++tries >= kMaxTries) { spec_p = p; spec = 2; }
+                if (accepted || ++spec > kMaxTries) { spec_p = p; spec = -1; }
             }
-            m_pend = ballot(spec == 1);
-            m_dir = ballot(stage == kNeedDir && spec != 2);
+            m_pend = ballot(spec > 0);
+            m_dir = ballot(stage == kNeedDir && spec >= 0);
             if (COUNT) d_time[3] += __builtin_amdgcn_s_memtime() - d_t0;
         }
         // lanes whose direction just became ready are S lanes now; they are picked up by the next trip's S vote
