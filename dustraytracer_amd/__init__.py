@@ -213,6 +213,7 @@ _sig("drt_renderer_set_stream", C.c_int, _P, _P)
 _sig("drt_renderer_set_counting", C.c_int, _P, C.c_int32)
 _sig("drt_renderer_get_counters", C.c_int, _P, C.POINTER(Counters))
 _sig("drt_renderer_kernel_info", C.c_int, _P, C.c_char_p, C.c_size_t)
+_sig("drt_renderer_kernel_span", C.c_int, _P, C.POINTER(C.c_float))
 _sig("drt_assemble_shards", C.c_int, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P)
 _sig("drt_shard_rows", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
 _sig("drt_debug_kat", C.c_int, C.c_int32, C.c_int32, _P, C.c_size_t, _P, C.c_size_t, C.c_uint32, C.POINTER(_CameraPOD), C.c_uint32, C.c_uint32)
@@ -419,6 +420,12 @@ class Renderer:
         c = Counters()
         _check(_lib.drt_renderer_get_counters(self._h, C.byref(c)))
         return c
+
+    def kernelSpanMs(self):
+        """Device-measured execution time of the tracing kernel(s) of the last completed batch (no queueing time)."""
+        ms = C.c_float(0)
+        _check(_lib.drt_renderer_kernel_span(self._h, C.byref(ms)))
+        return float(ms.value)
 
     def kernelInfo(self):
         buf = C.create_string_buffer(128)

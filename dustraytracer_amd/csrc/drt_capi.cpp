@@ -85,6 +85,11 @@ struct drt_renderer {
     bool counting = false;
     bool pending = false;                     // an asynchronous render was enqueued and not waited for yet
     unsigned long long *counters = nullptr;
+    static constexpr int kMaxSpans = 64;
+    unsigned long long *spans = nullptr;      // kMaxSpans x {max(~start), max(end)}: execution span of each wave_queue launch of the last batch
+    int spans_used = 0;
+    float span_ms = 0.f;                       // sum of those spans, filled by drt_renderer_wait
+    int wall_clock_khz = 100000;
     unsigned int *tile_counter = nullptr;     // work queue head of the wave_queue kernel
     void *samples = nullptr;                  // wave_queue: one float4 per (pixel, frame) of a launch
     size_t samples_bytes = 0;
@@ -284,8 +289,11 @@ drt_renderer *drt_renderer_create(int32_t device) {
     r->sample_budget = (size_t)std::max(1, env_int("DRT_SAMPLE_MB", 1024)) << 20;
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) r->num_cus = cus;
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) r->wall_clock_khz = khz;
     if (hipEventCreate(&r->ev_start) != hipSuccess || hipEventCreate(&r->ev_stop) != hipSuccess ||
         hipMalloc((void **)&r->counters, sizeof(drt_counters)) != hipSuccess ||
+        hipMalloc((void **)&r->spans, sizeof(unsigned long long) * 2 * drt_renderer::kMaxSpans) != hipSuccess ||
         hipMalloc((void **)&r->tile_counter, sizeof(unsigned int)) != hipSuccess) {
         fail(DRT_ERR_DEVICE, "cannot create HIP events / counter buffer");
         drt_renderer_destroy(r);
@@ -301,6 +309,7 @@ void drt_renderer_destroy(drt_renderer *r) {
     if (r->accum) (void)hipFree(r->accum);
     if (r->rgba) (void)hipFree(r->rgba);
     if (r->counters) (void)hipFree(r->counters);
+    if (r->spans) (void)hipFree(r->spans);
     if (r->tile_counter) (void)hipFree(r->tile_counter);
     if (r->samples) (void)hipFree(r->samples);
     if (r->ev_start) (void)hipEventDestroy(r->ev_start);
@@ -383,6 +392,12 @@ int drt_renderer_get_counters(drt_renderer *r, drt_counters *out) {
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->stream));
     HIP_TRY(hipMemcpy(out, r->counters, sizeof *out, hipMemcpyDeviceToHost));
+    return DRT_OK;
+}
+
+int drt_renderer_kernel_span(const drt_renderer *r, float *ms) {
+    if (!r || !ms) return fail(DRT_ERR_INVALID, "bad argument");
+    *ms = r->span_ms;
     return DRT_OK;
 }
 
@@ -499,9 +514,12 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
             HIP_TRY(hipMalloc(&r->samples, std::max<size_t>(need, 16)));
             r->samples_bytes = need;
         }
+        r->spans_used = 0;
+        HIP_TRY(hipMemsetAsync(r->spans, 0, sizeof(unsigned long long) * 2 * drt_renderer::kMaxSpans, r->stream));
         for (uint32_t done = 0; done < n_frames; done += frames_per_launch) {
             fp.frame_first = r->frame_index + done;
             fp.n_frames = std::min(frames_per_launch, n_frames - done);
+            fp.span = r->spans_used < drt_renderer::kMaxSpans ? r->spans + 2 * r->spans_used++ : nullptr;
             HIP_TRY(launch_wave_queue(r->view, fp, r->bvh_depth, r->counting ? 2 : 0, r->scene_has_alpha, r->tile_counter,
                                       r->samples, r->num_cus, r->stream, &r->kernel_name, r->launch_shape));
         }
@@ -531,6 +549,17 @@ int drt_renderer_wait(drt_renderer *r, float *delta_ms) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, r->ev_start, r->ev_stop));
     if (delta_ms) *delta_ms = ms;
+    r->span_ms = 0.f;
+    if (r->spans_used > 0) {
+        unsigned long long host[2 * drt_renderer::kMaxSpans];
+        HIP_TRY(hipMemcpy(host, r->spans, sizeof(unsigned long long) * 2 * (size_t)r->spans_used, hipMemcpyDeviceToHost));
+        double ticks = 0;
+        for (int i = 0; i < r->spans_used; i++) {
+            const unsigned long long start = ~host[2 * i], end = host[2 * i + 1];
+            if (host[2 * i] != 0 && end > start) ticks += (double)(end - start);
+        }
+        r->span_ms = (float)(ticks / (double)r->wall_clock_khz);
+    }
     r->pending = false;
     return DRT_OK;
 }

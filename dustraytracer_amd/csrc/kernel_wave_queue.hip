@@ -97,6 +97,9 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
     StackEntry(*stack)[kThreads] = reinterpret_cast<StackEntry(*)[kThreads]>(lds_raw);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    // The kernel's own execution span (first wave in to last wave out, constant-rate clock): what a profiler reports as
+    // the kernel's duration, also when launches from several streams share the GPU and stream events include queueing.
+    if (fp.span && lane == 0) atomicMax(&fp.span[0], ~(unsigned long long)wall_clock64());
 
     // ---- scene source: LDS copy (indexed in uint4 units from lds_raw) or HBM ----
     const uint32_t kSceneBase = stack_entries * (uint32_t)(kThreads * sizeof(StackEntry) / 16);
@@ -489,6 +492,7 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
         }
     }
 
+    if (fp.span && lane == 0) atomicMax(&fp.span[1], (unsigned long long)wall_clock64());
     if (COUNT && fp.counters) {
         atomicAdd(&fp.counters[0], c_samples); atomicAdd(&fp.counters[1], c_rays); atomicAdd(&fp.counters[2], c_nodes);
         atomicAdd(&fp.counters[3], c_inner); atomicAdd(&fp.counters[4], c_tris); atomicAdd(&fp.counters[5], c_htex);

@@ -180,6 +180,11 @@ int           drt_renderer_set_stream(drt_renderer *r, void *hip_stream);     /*
 int           drt_renderer_set_counting(drt_renderer *r, int32_t enable);     /* exact work counters (slower kernel) */
 int           drt_renderer_get_counters(drt_renderer *r, drt_counters *out);
 int           drt_renderer_kernel_info(const drt_renderer *r, char *buf, size_t cap);  /* name/variant of the last kernel */
+/* Execution time of the tracing kernel(s) of the last batch that drt_renderer_wait / a blocking render completed, as
+ * the kernel itself measured it (first wave in .. last wave out on the device's constant-rate clock).  Unlike the stream
+ * events behind *delta_ms it does not include time the launch spent queued behind other streams' work.  0 for the
+ * pixel_walk kernel. */
+int           drt_renderer_kernel_span(const drt_renderer *r, float *ms);
 /* rank-0 side of the gather: `gathered` = world shards of padded_rows rows each (as written by the ranks' device_rgba),
  * `image` = full width*height float4.  Runs on `hip_stream`. */
 int           drt_assemble_shards(const void *gathered, void *image, uint32_t width, uint32_t height,
