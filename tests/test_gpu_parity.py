@@ -407,3 +407,18 @@ def test_headless_cli_example_writes_the_image(tmp_path):
     ref, _, _ = oracle.render(osc, oracle.default_camera(position=pos, forward=fwd), oracle.default_settings(ray_bounce_limit=4), 96, 64, 1, 2)
     want = (np.clip(ref[::-1], 0, 1) * np.float32(255) + np.float32(0.5)).astype(np.uint8)
     assert np.array_equal(png, want)
+
+
+def test_kernel_span_is_within_the_stream_event_time(renderer):
+    """drt_renderer_kernel_span: the tracing kernel's own first-wave-in .. last-wave-out time; for a launch that has the GPU
+    to itself it must lie inside the HIP-event bracket around the launch (which also holds the resolve kernel)."""
+    sc, _ = make_pair("cornell_box")
+    cam, _ = cameras("cornell_box")
+    renderer.m_RendererSettings = drt.RendererSettings(ray_bounce_limit=8)
+    renderer.ResizeBuffer(640, 360)
+    for _ in range(3):
+        renderer.resetAccumulationBuffer()
+        ms = renderer.RenderBatch(cam, sc, 4)
+        span = renderer.kernelSpanMs()
+    assert 0.0 < span <= ms * 1.02 + 0.01, (span, ms)
+    assert span > 0.5 * ms, (span, ms)
