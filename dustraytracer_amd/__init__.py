@@ -433,7 +433,7 @@ class Renderer:
         return buf.value.decode()
 
 
-_KAT_WORDS = {0: (1, 5), 1: (1, 5), 2: (12, 1), 3: (15, 5), 4: (3, 7), 5: (1, 3)}
+_KAT_WORDS = {0: (1, 5), 1: (1, 5), 2: (12, 1), 3: (15, 5), 4: (3, 7), 5: (1, 3), 6: (10, 7)}
 
 
 def debug_kat(which, inputs, cam=None, width=0, height=0, device=0):

@@ -133,6 +133,14 @@ DRT_DEV float slab_intersect(f3 bmin, f3 bmax, const Ray &ray) {
     return tenter;
 }
 
+// ---- Kernel/Shaders/ClosestHit.cuh:13-24: hit position, and the face normal turned against the ray ----
+DRT_DEV bool closest_hit_frame(const Ray &ray, float t, f3 face_n, f3 &position, f3 &normal) {
+    position = ray.orig + ray.dir * t;                                       // :13
+    const bool back = dot(face_n, normalize(ray.dir)) > 0.f;                 // :17
+    normal = back ? (-1.f * face_n) : face_n;
+    return !back;                                                            // front_face
+}
+
 // ---- Kernel/Shaders/Intersection.cu:4-36 (edges precomputed: e1 = v1-v0, e2 = v2-v0) ----
 #define DRT_TRIANGLE_EPSILON 0.000001f     // Common/physical_units.hpp:12
 DRT_DEV bool tri_intersect(const Ray &ray, f3 v0, f3 e1, f3 e2, float &t_out, f3 &uvw) {

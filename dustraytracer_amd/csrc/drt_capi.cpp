@@ -610,7 +610,7 @@ int drt_debug_check_sqrt(int32_t device, uint64_t *mismatches, uint64_t *fast_pa
 
 int drt_debug_kat(int32_t device, int32_t which, const void *in, size_t in_bytes, void *out, size_t out_bytes, uint32_t n,
                   const drt_camera *cam, uint32_t width, uint32_t height) {
-    if (!in || !out || which < 0 || which > 5) return fail(DRT_ERR_INVALID, "bad argument");
+    if (!in || !out || which < 0 || which > 6) return fail(DRT_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(device));
     FrameParams fp;
     std::memset(&fp, 0, sizeof fp);

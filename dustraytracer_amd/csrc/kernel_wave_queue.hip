@@ -255,9 +255,8 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
                     path_done = true;
                 } else {
                     const f3 uvw = mk3(1.0f - hit_u - hit_v, hit_u, hit_v);                // Intersection.cu:31
-                    const f3 position = ray.orig + ray.dir * hit_t;                        // ClosestHit.cuh:13
-                    const f3 face_n = fetch_face_normal(hit_prim);
-                    const f3 normal = (dot(face_n, normalize(ray.dir)) > 0.f) ? (-1.f * face_n) : face_n;
+                    f3 position, normal;                                                   // ClosestHit.cuh:13-24
+                    closest_hit_frame(ray, hit_t, fetch_face_normal(hit_prim), position, normal);
                     const TriCold cold = fetch_cold(hit_prim);                             // :111-118
                     const MatDev mat = fetch_mat(cold.material);
                     if (mat.tex < 0) {

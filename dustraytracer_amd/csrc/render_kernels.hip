@@ -163,9 +163,8 @@ DRT_DEV f3 ray_gen(const SceneView &sc, const FrameParams &fp, uint32_t x, uint3
         }
 
         // ClosestHit.cuh:4-28
-        f3 position = ray.orig + ray.dir * hit.t;
-        f3 face_n = ld3(sc.tri_hot[hit.prim].fn);
-        f3 normal = (dot(face_n, normalize(ray.dir)) > 0.f) ? (-1.f * face_n) : face_n;
+        f3 position, normal;
+        closest_hit_frame(ray, hit.t, ld3(sc.tri_hot[hit.prim].fn), position, normal);
 
         const TriCold cold = sc.tri_cold[hit.prim];                                // :111-118
         const MatDev mat = sc.mats[cold.material];
@@ -280,6 +279,13 @@ __global__ __launch_bounds__(256) void kat_kernel(int which, const uint32_t *in,
         uint32_t seed = in[i];
         const f2 p = random_in_unit_disk(seed);
         fout[3 * i] = p.x; fout[3 * i + 1] = p.y; out[3 * i + 2] = seed;
+    } else if (which == 6) {                    // in: orig3, dir3, t, face_normal3 -> out: position3, normal3, front_face
+        const float *r = fin + 10 * i;
+        const Ray ray = make_ray(mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]));
+        f3 position, normal;
+        const bool front = closest_hit_frame(ray, r[6], mk3(r[7], r[8], r[9]), position, normal);
+        fout[7 * i] = position.x; fout[7 * i + 1] = position.y; fout[7 * i + 2] = position.z;
+        fout[7 * i + 3] = normal.x; fout[7 * i + 4] = normal.y; fout[7 * i + 5] = normal.z; out[7 * i + 6] = front ? 1u : 0u;
     }
 }
 

@@ -195,7 +195,7 @@ int           drt_debug_check_sqrt(int32_t device, uint64_t *mismatches, uint64_
 /* Device leaf functions on arrays, for known-answer tests against tests/golden/kat_ref.npz.
  * which: 0 unit vec (in u32 seed; out vec3,seed,tries), 1 unit sphere (same), 2 slab (in orig3,dir3,min3,max3; out f32),
  * 3 triangle (in orig3,dir3,v0,v1,v2; out t,U,V,W,hit), 4 camera ray (in u,v,seed; out orig3,dir3,seed; needs cam,width,height),
- * 5 unit disk (in seed; out x,y,seed). */
+ * 5 unit disk (in seed; out x,y,seed), 6 closest-hit frame (in orig3,dir3,t,face_normal3; out position3,normal3,front_face). */
 int           drt_debug_kat(int32_t device, int32_t which, const void *in, size_t in_bytes, void *out, size_t out_bytes, uint32_t n,
                             const drt_camera *cam, uint32_t width, uint32_t height);
 /* Every 32-bit value on a cycle of the RNG hash (Random.cu:6-11) no longer than max_len: (value, length) pairs. */

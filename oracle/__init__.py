@@ -266,6 +266,15 @@ def kat_intersect(rays6, tris9):
     return out, hit
 
 
+def kat_closest_hit(rays6, t, face_n3):
+    data = np.ascontiguousarray(np.concatenate([_f32(rays6).reshape(-1, 6), _f32(t).reshape(-1, 1), _f32(face_n3).reshape(-1, 3)], axis=1))
+    n = len(data)
+    out = np.zeros((n, 6), np.float32)
+    front = np.zeros(n, np.int32)
+    lib().o_kat_closest_hit(_ptr(data), C.c_int32(n), _ptr(out), _ptr(front))
+    return out[:, :3].copy(), out[:, 3:].copy(), front
+
+
 def kat_getray(cam, width, height, uv2, seeds):
     uv2, seeds = _f32(uv2), _u32(seeds)
     n = len(seeds)

@@ -334,6 +334,18 @@ static int traverse_bvh_raytest(const ray_t *ray, int root, const o_scene *sc, o
     return 0;
 }
 
+/* Shaders/ClosestHit.cuh:13-24: hit position, and the face normal turned against the ray.  Returns front_face. */
+static int closest_hit_frame(const ray_t *ray, float t, f3 fn, f3 *position, f3 *normal)
+{
+    *position = add3(ray->orig, scale3(ray->dir, t));                                       /* :13 */
+    if (dot3(fn, normalize3(ray->dir)) > 0.f) {                                             /* :17 */
+        *normal = scale3l(-1.f, fn);
+        return 0;
+    }
+    *normal = fn;
+    return 1;
+}
+
 /* ---- Kernel/TraceRay.cu:15-32, Shaders/ClosestHit.cuh:4-28, Shaders/Miss.cuh:2-6 ---- */
 static hit_payload trace_ray(const ray_t *ray, const o_scene *sc, o_counters *cnt)
 {
@@ -356,12 +368,7 @@ static hit_payload trace_ray(const ray_t *ray, const o_scene *sc, o_counters *cn
     out.prim = w.prim;                                   /* ClosestHit */
     out.uvw = w.uvw;
     out.t = w.t;
-    out.position = add3(ray->orig, scale3(ray->dir, w.t));
-    f3 fn = ld3(w.prim->face_n);
-    if (dot3(fn, normalize3(ray->dir)) > 0.f)
-        out.normal = scale3l(-1.f, fn);
-    else
-        out.normal = fn;
+    closest_hit_frame(ray, w.t, ld3(w.prim->face_n), &out.position, &out.normal);
     return out;
 }
 
@@ -913,6 +920,17 @@ void o_kat_intersect(const float *rays6, const float *tris9, int32_t n, float *o
         short_hit h = tri_intersect(&r, p);
         out4[4 * i] = h.t; out4[4 * i + 1] = h.uvw.x; out4[4 * i + 2] = h.uvw.y; out4[4 * i + 3] = h.uvw.z;
         hit[i] = h.hit;
+    }
+}
+
+void o_kat_closest_hit(const float *in10, int32_t n, float *out6, int32_t *front)
+{
+    for (int32_t i = 0; i < n; i++) {
+        const float *q = &in10[10 * i];
+        ray_t r = make_ray(ld3(&q[0]), ld3(&q[3]));
+        f3 pos, nrm;
+        front[i] = closest_hit_frame(&r, q[6], ld3(&q[7]), &pos, &nrm);
+        st3(&out6[6 * i], pos); st3(&out6[6 * i + 3], nrm);
     }
 }
 

@@ -6,7 +6,7 @@
  * build, load or call it.  The product (dustraytracer_amd/) never does.
  *
  * Parity status: the leaf arithmetic (RNG, camera ray, slab test,
- * Moller-Trumbore, texel fetch) is pinned bit-for-bit against a build of the
+ * Moller-Trumbore, closest-hit frame, texel fetch) is pinned bit-for-bit against a build of the
  * reference's own sources (oracle/_ref/ref_kat, see oracle/Makefile and
  * tests/golden/kat_*.npz).  The control-flow composition (BVH traversal,
  * TraceRay, RayGen, accumulate, BVH builder, glTF flattening) is a restatement
@@ -152,6 +152,8 @@ void o_kat_unit_disk(const uint32_t *seeds, int32_t n, float *out2, uint32_t *se
 void o_kat_slab(const float *rays6, const float *boxes6, int32_t n, float *out);
 /* Intersection.cu:4-36; tris9 = n x (v0,v1,v2); out4 = n x (t,U,V,W), hit[n] */
 void o_kat_intersect(const float *rays6, const float *tris9, int32_t n, float *out4, int32_t *hit);
+/* Shaders/ClosestHit.cuh:4-28; in10 = n x (origin3, dir3, t, face_normal3); out6 = n x (position3, normal3), front[n] */
+void o_kat_closest_hit(const float *in10, int32_t n, float *out6, int32_t *front);
 /* Camera.cu:82-123; uv2 = n x (u,v); out6 = n x (origin3, dir3) */
 void o_kat_get_ray(const o_camera *cam, const float *uv2, const uint32_t *seeds, int32_t n,
                    float width, float height, float *out6, uint32_t *seed_out);

@@ -65,6 +65,14 @@ def intersect(rays6, tris9):
     return out["tuvw"].copy(), out["hit"].copy()
 
 
+def closesthit(rays6, t, face_n3):
+    data = np.concatenate([np.asarray(rays6, "<f4").reshape(-1, 6), np.asarray(t, "<f4").reshape(-1, 1),
+                           np.asarray(face_n3, "<f4").reshape(-1, 3)], axis=1)
+    rec = np.dtype([("pos", "<f4", 3), ("normal", "<f4", 3), ("front", "<i4")])
+    out = np.frombuffer(_run("closesthit", np.ascontiguousarray(data).tobytes()), rec)
+    return out["pos"].copy(), out["normal"].copy(), out["front"].copy()
+
+
 def getray(cam, width, height, uv2, seeds):
     """cam = (exposure, vfov_rad, defocus_angle, focus_dist, pos3, fwd3)"""
     head = np.array([cam[0], cam[1], cam[2], cam[3], *cam[4], *cam[5], width, height], "<f4")

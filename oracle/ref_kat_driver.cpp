@@ -4,7 +4,8 @@
 // straight from /root/reference/DustRayTracer/src (see oracle/Makefile, target
 // _ref/ref_kat): Core/Bounds.cu, Core/CudaMath/Random.cu,
 // Core/Kernel/Shaders/Intersection.cu, Core/Scene/Camera.cu,
-// Core/Scene/Texture.cu, Core/Interval.cu.  Headers come from the image: the
+// Core/Scene/Texture.cu, Core/Interval.cu, and the header-only
+// Core/Kernel/Shaders/ClosestHit.cuh.  Headers come from the image: the
 // CUDA toolkit headers bundled with triton, glm and stb_image vendored by the
 // reference.  No stand-in headers or libraries are written; the few CUDA runtime
 // symbols referenced by code paths we never call stay unresolved.
@@ -17,6 +18,8 @@
 #include "Core/Scene/Camera.cuh"
 #include "Core/Scene/Texture.cuh"
 #include "Core/Scene/Triangle.cuh"
+#include "Core/HitPayload.cuh"
+#include "Core/Kernel/Shaders/ClosestHit.cuh"
 
 #include <cstdio>
 #include <cstring>
@@ -92,6 +95,18 @@ int main(int argc, char **argv)
             // UVW is left uninitialised by the reference on a miss
             out.put(hit ? p.UVW.x : 0.f); out.put(hit ? p.UVW.y : 0.f); out.put(hit ? p.UVW.z : 0.f);
             out.put(hit);
+        }
+    } else if (fn == "closesthit") {                     // in: n x (orig3, dir3, t, face_normal3) -> out: n x (pos3, normal3, i32 front_face)
+        for (size_t i = 0; i + 10 <= in.size() / 4; i += 10) {
+            Ray r(make_float3(fin[i], fin[i + 1], fin[i + 2]), make_float3(fin[i + 3], fin[i + 4], fin[i + 5]));
+            Triangle t;
+            t.face_normal = make_float3(fin[i + 7], fin[i + 8], fin[i + 9]);
+            HitPayload hit;
+            hit.hit_distance = fin[i + 6];
+            hit.primitiveptr = &t;
+            hit.UVW = make_float3(0, 0, 0);
+            HitPayload p = ClosestHit(r, &hit);
+            out.put3(p.world_position); out.put3(p.world_normal); out.put((int32_t)p.front_face);
         }
     } else if (fn == "getray") {
         // in: exposure, vfov_rad, defocus_angle, focus_dist, pos3, fwd3, width, height, then n x (u, v, u32 seed)

@@ -82,6 +82,17 @@ def kat_inputs(seed=20240807, n=4096):
     tuv = rng.uniform(-3, 3, (n, 2)).astype(np.float32)
     tuv[:8] = [[0, 0], [1, 1], [-1, -1], [0.999999, 0.5], [-1e-9, 0.5], [0.5, -1e-9], [2.5, -2.5], [1e-9, 1e-9]]
     d["tex3"], d["tex4"], d["tex_uv"] = tex3, tex4, tuv
+
+    # ClosestHit: rays as above, hit distances, unit face normals; a block with the normal exactly perpendicular to the
+    # ray (dot == 0 -> front face) and one with tiny directions (normalize of a denormal-ish vector)
+    fn = rng.normal(size=(n, 3)).astype(np.float32)
+    fn /= np.linalg.norm(fn, axis=1, keepdims=True).astype(np.float32)
+    ch_rays = np.concatenate([rng.uniform(-5, 5, (n, 3)), rng.uniform(-1, 1, (n, 3))], 1).astype(np.float32)
+    ch_rays[:64, 3:] = np.array([1, 0, 0], np.float32)
+    fn[:32] = np.array([0, 1, 0], np.float32)
+    fn[32:64] = np.array([0, 0, -1], np.float32)
+    ch_rays[64:128, 3:] *= np.float32(1e-18)
+    d["ch_rays"], d["ch_t"], d["ch_fn"] = ch_rays, rng.uniform(1e-3, 50, n).astype(np.float32), fn
     return d
 
 
@@ -98,6 +109,7 @@ def main():
     out["unitdisk"], out["unitdisk_seed"] = rk.unitdisk(d["seeds"])
     out["slab"] = rk.slab(d["slab_rays"], d["slab_boxes"])
     out["isect_tuvw"], out["isect_hit"] = rk.intersect(d["isect_rays"], d["isect_tris"])
+    out["ch_pos"], out["ch_normal"], out["ch_front"] = rk.closesthit(d["ch_rays"], d["ch_t"], d["ch_fn"])
     rays, rseeds = [], []
     for cam in d["cams"]:
         r, s = rk.getray((cam[0], cam[1], cam[2], cam[3], cam[4:7], cam[7:10]), cam[10], cam[11], d["uv"], d["seeds"])

@@ -48,6 +48,15 @@ def test_device_triangle_test_matches_reference(kat_golden):
     assert np.array_equal(out[hit, :4], bits(g["isect_tuvw"])[hit])      # t, U, V, W of the straight-line test + exact_rcp
 
 
+def test_device_closest_hit_frame_matches_reference(kat_golden):
+    g = kat_golden
+    inp = np.concatenate([g["ch_rays"], g["ch_t"][:, None], g["ch_fn"]], axis=1).astype(np.float32)
+    out = drt.debug_kat(6, inp)
+    assert np.array_equal(out[:, :3], bits(g["ch_pos"]))
+    assert np.array_equal(out[:, 3:6], bits(g["ch_normal"]))
+    assert np.array_equal(out[:, 6].astype(np.int32), g["ch_front"])
+
+
 def test_device_camera_ray_matches_reference(kat_golden):
     g = kat_golden
     for k, c in enumerate(g["cams"]):

@@ -94,6 +94,16 @@ def test_intersection_matches_reference(kat_golden):
     assert hit[256:304].all() and not hit[304:320].any()
 
 
+def test_closest_hit_matches_reference(kat_golden):
+    g = kat_golden
+    pos, nrm, front = oracle.kat_closest_hit(g["ch_rays"], g["ch_t"], g["ch_fn"])
+    assert np.array_equal(front, g["ch_front"])
+    assert np.array_equal(bits(pos), bits(g["ch_pos"]))
+    assert np.array_equal(bits(nrm), bits(g["ch_normal"]))
+    assert front[:64].all()                      # dot == 0: the strict > keeps the face normal (ClosestHit.cuh:17)
+    assert 0.3 < front.mean() < 0.7
+
+
 def test_get_ray_matches_reference(kat_golden):
     g = kat_golden
     for k, cam in enumerate(g["cams"]):
