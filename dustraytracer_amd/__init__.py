@@ -101,20 +101,20 @@ class Camera:
         return self.m_Position.copy()
 
     def OnUpdate(self, velocity, delta):
-        """Camera.cu:44-58: move along the camera basis."""
-        basis = np.stack([self.m_Right_dir, self.m_Up_dir, self.m_Forward_dir], axis=1).astype(np.float32)
-        move = basis @ np.asarray(velocity, np.float32)
-        self.m_Position = (self.m_Position + np.float32(self.m_movement_speed) * move * np.float32(delta)).astype(np.float32)
+        """Camera.cu:44-58: move along the camera basis (the C ABI's implementation: fp32, the reference's order)."""
+        v = np.ascontiguousarray(velocity, np.float32)
+        self.m_Position = np.ascontiguousarray(self.m_Position, np.float32)
+        r, u, f = (np.ascontiguousarray(a, np.float32) for a in (self.m_Right_dir, self.m_Up_dir, self.m_Forward_dir))
+        _lib.drt_camera_move(self.m_Position.ctypes.data, r.ctypes.data, u.ctypes.data, f.ctypes.data, v.ctypes.data,
+                             C.c_float(self.m_movement_speed), C.c_float(delta))
 
     def Rotate(self, delta):
         """Camera.cu:61-80: delta = (sin_x, cos_x, sin_y, cos_y)."""
-        sx, cx, sy, cy = (np.float32(v) for v in delta)
-        f, up = self.m_Forward_dir, self.m_Up_dir
-        f = f * cx + np.cross(up, f) * sx + up * np.dot(up, f) * (1 - cx)
-        r = self.m_Right_dir
-        f = f * cy + np.cross(r, f) * sy + r * np.dot(r, f) * (1 - cy)
-        self.m_Forward_dir = f.astype(np.float32)
-        self.m_Right_dir = np.cross(self.m_Forward_dir, up).astype(np.float32)
+        d = np.ascontiguousarray(delta, np.float32)
+        self.m_Forward_dir = np.ascontiguousarray(self.m_Forward_dir, np.float32)
+        self.m_Right_dir = np.ascontiguousarray(self.m_Right_dir, np.float32)
+        u = np.ascontiguousarray(self.m_Up_dir, np.float32)
+        _lib.drt_camera_rotate(self.m_Forward_dir.ctypes.data, self.m_Right_dir.ctypes.data, u.ctypes.data, d.ctypes.data)
 
     def _pod(self):
         pod = _CameraPOD()
@@ -177,6 +177,8 @@ _sig("drt_last_error", C.c_char_p)
 _sig("drt_device_count", C.c_int)
 _sig("drt_default_settings", None, C.POINTER(RendererSettings))
 _sig("drt_default_camera", None, C.POINTER(_CameraPOD))
+_sig("drt_camera_rotate", None, _P, _P, _P, _P)
+_sig("drt_camera_move", None, _P, _P, _P, _P, _P, C.c_float, C.c_float)
 _sig("drt_scene_create", _P)
 _sig("drt_scene_destroy", None, _P)
 _sig("drt_scene_load_gltf", C.c_int, _P, C.c_char_p)

@@ -395,6 +395,36 @@ int drt_renderer_get_counters(drt_renderer *r, drt_counters *out) {
     return DRT_OK;
 }
 
+// Camera.cu:61-80.  helper_math.cuh: cross(a,b) = (a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x),
+// dot = a.x*b.x + a.y*b.y + a.z*b.z; every product and sum rounds on its own (-ffp-contract=off).
+static void rotate_about(float v[3], const float k[3], float s, float c) {
+    const float kxv[3] = { k[1] * v[2] - k[2] * v[1], k[2] * v[0] - k[0] * v[2], k[0] * v[1] - k[1] * v[0] };
+    const float d = k[0] * v[0] + k[1] * v[1] + k[2] * v[2];
+    const float one_minus_c = 1 - c;
+    float r[3];
+    for (int i = 0; i < 3; i++) r[i] = ((v[i] * c) + (kxv[i] * s)) + ((k[i] * d) * one_minus_c);
+    for (int i = 0; i < 3; i++) v[i] = r[i];
+}
+
+void drt_camera_rotate(float forward[3], float right[3], const float up[3], const float delta[4]) {
+    if (!forward || !right || !up || !delta) return;
+    rotate_about(forward, up, delta[0], delta[1]);
+    rotate_about(forward, right, delta[2], delta[3]);
+    const float r[3] = { forward[1] * up[2] - forward[2] * up[1], forward[2] * up[0] - forward[0] * up[2],
+                         forward[0] * up[1] - forward[1] * up[0] };
+    for (int i = 0; i < 3; i++) right[i] = r[i];
+}
+
+// Camera.cu:44-58 (glm::mat3 * vec3 = col0*v.x + col1*v.y + col2*v.z, then m_Position += speed * move * delta)
+void drt_camera_move(float position[3], const float right[3], const float up[3], const float forward[3],
+                     const float velocity[3], float speed, float delta) {
+    if (!position || !right || !up || !forward || !velocity) return;
+    for (int i = 0; i < 3; i++) {
+        const float move = (right[i] * velocity[0] + up[i] * velocity[1]) + forward[i] * velocity[2];
+        position[i] = position[i] + (speed * move) * delta;
+    }
+}
+
 int drt_renderer_kernel_span(const drt_renderer *r, float *ms) {
     if (!r || !ms) return fail(DRT_ERR_INVALID, "bad argument");
     *ms = r->span_ms;

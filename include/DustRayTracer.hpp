@@ -71,16 +71,10 @@ public:
     explicit Camera(float3_ pos = { 0, 2, 5 }) : m_Position(pos) { m_Right_dir = cross(m_Forward_dir, m_Up_dir); }
 
     void OnUpdate(float3_ velocity, float delta) {                       // Camera.cu:44-58
-        float3_ v = { m_Right_dir.x * velocity.x + m_Up_dir.x * velocity.y + m_Forward_dir.x * velocity.z,
-                      m_Right_dir.y * velocity.x + m_Up_dir.y * velocity.y + m_Forward_dir.y * velocity.z,
-                      m_Right_dir.z * velocity.x + m_Up_dir.z * velocity.y + m_Forward_dir.z * velocity.z };
-        m_Position = { m_Position.x + m_movement_speed * v.x * delta, m_Position.y + m_movement_speed * v.y * delta,
-                       m_Position.z + m_movement_speed * v.z * delta };
+        drt_camera_move(&m_Position.x, &m_Right_dir.x, &m_Up_dir.x, &m_Forward_dir.x, &velocity.x, m_movement_speed, delta);
     }
     void Rotate(float4_ d) {                                             // Camera.cu:61-80 (sin_x, cos_x, sin_y, cos_y)
-        m_Forward_dir = rodrigues(m_Forward_dir, m_Up_dir, d.x, d.y);
-        m_Forward_dir = rodrigues(m_Forward_dir, m_Right_dir, d.z, d.w);
-        m_Right_dir = cross(m_Forward_dir, m_Up_dir);
+        drt_camera_rotate(&m_Forward_dir.x, &m_Right_dir.x, &m_Up_dir.x, &d.x);
     }
     float3_ GetPosition() const { return m_Position; }
     void setMovementSpeed(float speed) { m_movement_speed = speed; }
@@ -106,12 +100,6 @@ public:
 
 private:
     static float3_ cross(float3_ a, float3_ b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
-    static float dot(float3_ a, float3_ b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-    static float3_ rodrigues(float3_ v, float3_ k, float s, float c) {
-        float3_ kxv = cross(k, v);
-        float kv = dot(k, v) * (1 - c);
-        return { v.x * c + kxv.x * s + k.x * kv, v.y * c + kxv.y * s + k.y * kv, v.z * c + kxv.z * s + k.z * kv };
-    }
 };
 
 // Core/Scene/Scene.cuh:41-57

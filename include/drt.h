@@ -118,6 +118,12 @@ const char *drt_last_error(void);
 int         drt_device_count(void);                       /* usable HIP devices, 0 when none */
 void        drt_default_settings(drt_settings *out);      /* RendererSettings.h:22-34 */
 void        drt_default_camera(drt_camera *out);          /* Camera.cuh:32-46 + EditorLayer.cpp:35-40 */
+/* Camera host logic, one implementation for every binding (fp32, the reference's operation order):
+ * Camera::Rotate (Camera.cu:61-80; delta = sin_x, cos_x, sin_y, cos_y) updates forward and right in place;
+ * Camera::OnUpdate (Camera.cu:44-58) moves position by speed * (right*v.x + up*v.y + forward*v.z) * delta. */
+void        drt_camera_rotate(float forward[3], float right[3], const float up[3], const float delta[4]);
+void        drt_camera_move(float position[3], const float right[3], const float up[3], const float forward[3],
+                            const float velocity[3], float speed, float delta);
 
 /* ---- Scene: host-side load + BVH build (Scene.cu:181-317, BVHBuilder.cu:11-92) ---- */
 drt_scene *drt_scene_create(void);

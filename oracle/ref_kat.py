@@ -73,6 +73,13 @@ def closesthit(rays6, t, face_n3):
     return out["pos"].copy(), out["normal"].copy(), out["front"].copy()
 
 
+def cammove(pos, fwd, up, right, speed, steps8):
+    """steps8 = n x (sin_x, cos_x, sin_y, cos_y, vel3, delta); returns n x (pos3, fwd3, right3) after each OnUpdate + Rotate."""
+    head = np.array([*pos, *fwd, *up, *right, speed], "<f4")
+    out = np.frombuffer(_run("cammove", head.tobytes() + np.asarray(steps8, "<f4").reshape(-1, 8).tobytes()), "<f4")
+    return out.reshape(-1, 9).copy()
+
+
 def getray(cam, width, height, uv2, seeds):
     """cam = (exposure, vfov_rad, defocus_angle, focus_dist, pos3, fwd3)"""
     head = np.array([cam[0], cam[1], cam[2], cam[3], *cam[4], *cam[5], width, height], "<f4")

@@ -108,6 +108,19 @@ int main(int argc, char **argv)
             HitPayload p = ClosestHit(r, &hit);
             out.put3(p.world_position); out.put3(p.world_normal); out.put((int32_t)p.front_face);
         }
+    } else if (fn == "cammove") {
+        // Camera::Rotate / Camera::OnUpdate (host logic, Camera.cu:44-80) applied in sequence to one camera.
+        // in: pos3, fwd3, up3, right3, speed, then n x (sin_x, cos_x, sin_y, cos_y, vel3, delta) -> out: n x (pos3, fwd3, right3)
+        Camera cam(make_float3(fin[0], fin[1], fin[2]));
+        cam.m_Forward_dir = make_float3(fin[3], fin[4], fin[5]);
+        cam.m_Up_dir = make_float3(fin[6], fin[7], fin[8]);
+        cam.m_Right_dir = make_float3(fin[9], fin[10], fin[11]);
+        cam.setMovementSpeed(fin[12]);
+        for (size_t i = 13; i + 8 <= in.size() / 4; i += 8) {
+            cam.OnUpdate(make_float3(fin[i + 4], fin[i + 5], fin[i + 6]), fin[i + 7]);          // EditorLayer.cpp:400-401 order
+            cam.Rotate(make_float4(fin[i], fin[i + 1], fin[i + 2], fin[i + 3]));
+            out.put3(cam.GetPosition()); out.put3(cam.m_Forward_dir); out.put3(cam.m_Right_dir);
+        }
     } else if (fn == "getray") {
         // in: exposure, vfov_rad, defocus_angle, focus_dist, pos3, fwd3, width, height, then n x (u, v, u32 seed)
         Camera cam(make_float3(fin[4], fin[5], fin[6]));

@@ -93,6 +93,16 @@ def kat_inputs(seed=20240807, n=4096):
     fn[32:64] = np.array([0, 0, -1], np.float32)
     ch_rays[64:128, 3:] *= np.float32(1e-18)
     d["ch_rays"], d["ch_t"], d["ch_fn"] = ch_rays, rng.uniform(1e-3, 50, n).astype(np.float32), fn
+
+    # Camera::OnUpdate + Camera::Rotate, 512 editor frames in sequence (mouse deltas as sin/cos of small angles)
+    m = 512
+    ax, ay = rng.uniform(-0.05, 0.05, m).astype(np.float32), rng.uniform(-0.05, 0.05, m).astype(np.float32)
+    steps = np.zeros((m, 8), np.float32)
+    steps[:, 0], steps[:, 1], steps[:, 2], steps[:, 3] = np.sin(ax), np.cos(ax), np.sin(ay), np.cos(ay)
+    steps[:, 4:7] = rng.integers(-1, 2, (m, 3)).astype(np.float32)
+    steps[:, 7] = rng.uniform(0.001, 0.03, m).astype(np.float32)
+    d["cam_steps"] = steps
+    d["cam_start"] = np.array([0, 2, 5, 0, 0, -1, 0, 1, 0, 1, 0, 0, 10], np.float32)   # pos, fwd, up, right, speed
     return d
 
 
@@ -110,6 +120,8 @@ def main():
     out["slab"] = rk.slab(d["slab_rays"], d["slab_boxes"])
     out["isect_tuvw"], out["isect_hit"] = rk.intersect(d["isect_rays"], d["isect_tris"])
     out["ch_pos"], out["ch_normal"], out["ch_front"] = rk.closesthit(d["ch_rays"], d["ch_t"], d["ch_fn"])
+    c = d["cam_start"]
+    out["cam_track"] = rk.cammove(c[0:3], c[3:6], c[6:9], c[9:12], c[12], d["cam_steps"])
     rays, rseeds = [], []
     for cam in d["cams"]:
         r, s = rk.getray((cam[0], cam[1], cam[2], cam[3], cam[4:7], cam[7:10]), cam[10], cam[11], d["uv"], d["seeds"])

@@ -139,3 +139,20 @@ def test_degenerate_bvh_input_is_an_error_not_a_hang():
     with pytest.raises(drt.DrtError) as e:
         b.buildIterative(sc)
     assert e.value.code == drt.ERR_BVH
+
+
+def test_camera_host_logic_matches_reference(kat_golden):
+    """Camera::OnUpdate + Camera::Rotate (Camera.cu:44-80) over 512 editor frames: position, forward and right equal the
+    reference's own compiled code bit for bit (tests/golden/kat_ref.npz `cam_track`, made by oracle/_ref/ref_kat)."""
+    import dustraytracer_amd as drt
+    g = kat_golden
+    c = g["cam_start"]
+    cam = drt.Camera(c[0:3])
+    cam.m_Forward_dir, cam.m_Up_dir, cam.m_Right_dir = c[3:6].copy(), c[6:9].copy(), c[9:12].copy()
+    cam.m_movement_speed = float(c[12])
+    for k, st in enumerate(g["cam_steps"]):
+        cam.OnUpdate(st[4:7], float(st[7]))                 # EditorLayer.cpp:400-401 order
+        cam.Rotate(st[0:4])
+        got = np.concatenate([cam.m_Position, cam.m_Forward_dir, cam.m_Right_dir]).astype(np.float32)
+        assert np.array_equal(bits(got), bits(g["cam_track"][k])), k
+    assert np.linalg.norm(g["cam_track"][-1][:3] - c[0:3]) > 0.1
