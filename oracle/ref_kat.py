@@ -80,6 +80,11 @@ def cammove(pos, fwd, up, right, speed, steps8):
     return out.reshape(-1, 9).copy()
 
 
+def layout():
+    """{key: int} -- struct sizes / offsets and default member values (floats as bit patterns) of the reference's headers."""
+    return {k: int(v) for k, v in (line.split("=") for line in _run("layout", b"").decode().splitlines() if line)}
+
+
 def getray(cam, width, height, uv2, seeds):
     """cam = (exposure, vfov_rad, defocus_angle, focus_dist, pos3, fwd3)"""
     head = np.array([cam[0], cam[1], cam[2], cam[3], *cam[4], *cam[5], width, height], "<f4")

@@ -20,6 +20,11 @@
 #include "Core/Scene/Triangle.cuh"
 #include "Core/HitPayload.cuh"
 #include "Core/Kernel/Shaders/ClosestHit.cuh"
+#include "Core/BVH/BVHNode.cuh"
+#include "Core/Scene/Material.cuh"
+#include "Core/Scene/Mesh.cuh"
+#include "Core/Scene/RendererSettings.h"
+#include <cstddef>
 
 #include <cstdio>
 #include <cstring>
@@ -121,6 +126,42 @@ int main(int argc, char **argv)
             cam.Rotate(make_float4(fin[i], fin[i + 1], fin[i + 2], fin[i + 3]));
             out.put3(cam.GetPosition()); out.put3(cam.m_Forward_dir); out.put3(cam.m_Right_dir);
         }
+    } else if (fn == "layout") {
+        // sizes / field offsets of the structs the C ABI mirrors, and the default member values of settings and camera
+        // (as "key=value" lines; floats as their bit patterns)
+        auto kv = [&](const char *k, long long v) { char b[128]; int n = snprintf(b, sizeof b, "%s=%lld\n", k, v); out.b.insert(out.b.end(), b, b + n); };
+        auto kf = [&](const char *k, float v) { uint32_t u; memcpy(&u, &v, 4); kv(k, (long long)u); };
+        kv("sizeof_Vertex", sizeof(Vertex)); kv("Vertex.position", offsetof(Vertex, position)); kv("Vertex.normal", offsetof(Vertex, normal)); kv("Vertex.UV", offsetof(Vertex, UV));
+        kv("sizeof_Triangle", sizeof(Triangle)); kv("Triangle.centroid", offsetof(Triangle, centroid)); kv("Triangle.vertex0", offsetof(Triangle, vertex0));
+        kv("Triangle.vertex1", offsetof(Triangle, vertex1)); kv("Triangle.vertex2", offsetof(Triangle, vertex2));
+        kv("Triangle.face_normal", offsetof(Triangle, face_normal)); kv("Triangle.materialIdx", offsetof(Triangle, materialIdx));
+        kv("sizeof_BVHNode", sizeof(BVHNode)); kv("BVHNode.m_IsLeaf", offsetof(BVHNode, m_IsLeaf)); kv("BVHNode.m_BoundingBox", offsetof(BVHNode, m_BoundingBox));
+        kv("BVHNode.dev_child1_idx", offsetof(BVHNode, dev_child1_idx)); kv("BVHNode.dev_child2_idx", offsetof(BVHNode, dev_child2_idx));
+        kv("BVHNode.primitives_count", offsetof(BVHNode, primitives_count)); kv("BVHNode.primitive_start_idx", offsetof(BVHNode, primitive_start_idx));
+        kv("BVHNode.rayint_cost", BVHNode::rayint_cost); kv("BVHNode.trav_cost", BVHNode::trav_cost);
+        kv("sizeof_Material", sizeof(Material)); kv("Material.Albedo", offsetof(Material, Albedo)); kv("Material.EmmisiveFactor", offsetof(Material, EmmisiveFactor));
+        kv("Material.AlbedoTextureIndex", offsetof(Material, AlbedoTextureIndex)); kv("Material.Roughness", offsetof(Material, Roughness));
+        kv("Material.Transmission", offsetof(Material, Transmission)); kv("Material.refractive_index", offsetof(Material, refractive_index));
+        kv("Material.Metallic", offsetof(Material, Metallic));
+        Material m;
+        kf("Material.default.Albedo.x", m.Albedo.x); kv("Material.default.AlbedoTextureIndex", m.AlbedoTextureIndex); kf("Material.default.refractive_index", m.refractive_index);
+        RendererSettings rs;
+        kv("settings.gamma_correction", rs.gamma_correction); kv("settings.tone_mapping", rs.tone_mapping); kv("settings.enableSunlight", rs.enableSunlight);
+        kv("settings.max_samples", rs.max_samples); kv("settings.ray_bounce_limit", rs.ray_bounce_limit);
+        kv("settings.RenderMode", (int)rs.RenderMode); kv("settings.DebugMode", (int)rs.DebugMode);
+        kf("settings.sunlight_dir.x", rs.sunlight_dir.x); kf("settings.sunlight_dir.y", rs.sunlight_dir.y);
+        kf("settings.sunlight_color.x", rs.sunlight_color.x); kf("settings.sunlight_color.y", rs.sunlight_color.y); kf("settings.sunlight_color.z", rs.sunlight_color.z);
+        kf("settings.sunlight_intensity", rs.sunlight_intensity);
+        kf("settings.sky_color.x", rs.sky_color.x); kf("settings.sky_color.y", rs.sky_color.y); kf("settings.sky_color.z", rs.sky_color.z);
+        kf("settings.sky_intensity", rs.sky_intensity);
+        Camera cam;
+        kf("camera.exposure", cam.exposure); kf("camera.vfov_rad", cam.vfov_rad); kf("camera.defocus_angle", cam.defocus_angle);
+        kf("camera.focus_dist", cam.focus_dist); kf("camera.m_movement_speed", cam.m_movement_speed);
+        kf("camera.m_Position.x", cam.m_Position.x); kf("camera.m_Position.y", cam.m_Position.y); kf("camera.m_Position.z", cam.m_Position.z);
+        kf("camera.m_Forward_dir.x", cam.m_Forward_dir.x); kf("camera.m_Forward_dir.y", cam.m_Forward_dir.y); kf("camera.m_Forward_dir.z", cam.m_Forward_dir.z);
+        kf("camera.m_Up_dir.x", cam.m_Up_dir.x); kf("camera.m_Up_dir.y", cam.m_Up_dir.y); kf("camera.m_Up_dir.z", cam.m_Up_dir.z);
+        kf("camera.m_Right_dir.x", cam.m_Right_dir.x); kf("camera.m_Right_dir.y", cam.m_Right_dir.y); kf("camera.m_Right_dir.z", cam.m_Right_dir.z);
+        kf("deg2rad_60", deg2rad(60));
     } else if (fn == "getray") {
         // in: exposure, vfov_rad, defocus_angle, focus_dist, pos3, fwd3, width, height, then n x (u, v, u32 seed)
         Camera cam(make_float3(fin[4], fin[5], fin[6]));

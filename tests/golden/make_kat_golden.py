@@ -132,6 +132,9 @@ def main():
     out["texpixel4"] = rk.texpixel(d["tex4"], d["tex_uv"])
     out["texalpha4"] = rk.texalpha(d["tex4"], d["tex_uv"])
     out["texalpha3"] = rk.texalpha(d["tex3"], d["tex_uv"])
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_layout.json"), "w") as f:
+        json.dump(rk.layout(), f, indent=1, sort_keys=True)
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "kat_ref.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;",

@@ -72,3 +72,112 @@ def test_cpp_wrapper_compiles_and_links(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True)          # no arguments: usage, exit code 2
     assert r.returncode == 2 and "usage" in r.stderr
+
+
+def _ref_layout():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "ref_layout.json")))
+
+
+def test_pod_layouts_match_the_reference_headers(tmp_path):
+    """include/drt.h's PODs have the sizes and field offsets of the reference's own structs (Vertex, Triangle, BVHNode,
+    Material as its compiler lays them out: tests/golden/ref_layout.json, written by oracle/_ref/ref_kat `layout`), so
+    m_PrimitivesBuffer / m_BVHNodes / m_Material can be handed over as they are."""
+    src = tmp_path / "layout.c"
+    src.write_text(r"""
+#include <stddef.h>
+#include <stdio.h>
+#include "drt.h"
+#define P(k, v) printf("%s=%lld\n", k, (long long)(v))
+int main(void) {
+    P("sizeof_Vertex", sizeof(drt_vertex)); P("Vertex.position", offsetof(drt_vertex, position)); P("Vertex.normal", offsetof(drt_vertex, normal)); P("Vertex.UV", offsetof(drt_vertex, uv));
+    P("sizeof_Triangle", sizeof(drt_triangle)); P("Triangle.centroid", offsetof(drt_triangle, centroid)); P("Triangle.vertex0", offsetof(drt_triangle, vertex[0]));
+    P("Triangle.vertex1", offsetof(drt_triangle, vertex[1])); P("Triangle.vertex2", offsetof(drt_triangle, vertex[2]));
+    P("Triangle.face_normal", offsetof(drt_triangle, face_normal)); P("Triangle.materialIdx", offsetof(drt_triangle, material));
+    P("sizeof_BVHNode", sizeof(drt_bvh_node)); P("BVHNode.m_IsLeaf", offsetof(drt_bvh_node, is_leaf)); P("BVHNode.m_BoundingBox", offsetof(drt_bvh_node, bmin));
+    P("BVHNode.dev_child1_idx", offsetof(drt_bvh_node, child1)); P("BVHNode.dev_child2_idx", offsetof(drt_bvh_node, child2));
+    P("BVHNode.primitives_count", offsetof(drt_bvh_node, prim_count)); P("BVHNode.primitive_start_idx", offsetof(drt_bvh_node, prim_start));
+    P("sizeof_Material", sizeof(drt_material)); P("Material.Albedo", offsetof(drt_material, albedo)); P("Material.EmmisiveFactor", offsetof(drt_material, emissive));
+    P("Material.AlbedoTextureIndex", offsetof(drt_material, albedo_tex)); P("Material.Roughness", offsetof(drt_material, roughness));
+    P("Material.Transmission", offsetof(drt_material, transmission)); P("Material.refractive_index", offsetof(drt_material, refractive_index));
+    P("Material.Metallic", offsetof(drt_material, metallic));
+    return 0;
+}
+""")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    ours = dict(line.split("=") for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split())
+    ref = _ref_layout()
+    assert len(ours) == 26
+    for k, v in ours.items():
+        assert int(v) == ref[k], (k, v, ref[k])
+    # the numpy views the Python mirror hands out use the same offsets
+    assert drt.TRIANGLE_DTYPE.itemsize == ref["sizeof_Triangle"] and drt.TRIANGLE_DTYPE.fields["vertex"][1] == ref["Triangle.vertex0"]
+    assert drt.TRIANGLE_DTYPE.fields["face_normal"][1] == ref["Triangle.face_normal"] and drt.TRIANGLE_DTYPE.fields["material"][1] == ref["Triangle.materialIdx"]
+    assert drt.NODE_DTYPE.itemsize == ref["sizeof_BVHNode"] and drt.NODE_DTYPE.fields["child1"][1] == ref["BVHNode.dev_child1_idx"]
+    assert drt.NODE_DTYPE.fields["prim_start"][1] == ref["BVHNode.primitive_start_idx"]
+    assert drt.MATERIAL_DTYPE.itemsize == ref["sizeof_Material"] and drt.MATERIAL_DTYPE.fields["albedo_tex"][1] == ref["Material.AlbedoTextureIndex"]
+
+
+def test_defaults_match_the_reference_headers():
+    """drt_default_settings / drt_default_camera / Camera() = the default member initialisers of RendererSettings.h:22-34
+    and Camera.cuh:32-46, compared as bit patterns."""
+    import numpy as np
+    ref = _ref_layout()
+    f = lambda x: int(np.float32(x).view(np.uint32))
+    s = drt.RendererSettings()
+    for k, v in [("gamma_correction", s.gamma_correction), ("tone_mapping", s.tone_mapping), ("enableSunlight", s.enableSunlight),
+                 ("max_samples", s.max_samples), ("ray_bounce_limit", s.ray_bounce_limit), ("RenderMode", s.RenderMode), ("DebugMode", s.DebugMode)]:
+        assert int(v) == ref["settings." + k], k
+    for k, v in [("sunlight_dir.x", s.sunlight_dir[0]), ("sunlight_dir.y", s.sunlight_dir[1]), ("sunlight_color.x", s.sunlight_color[0]),
+                 ("sunlight_color.y", s.sunlight_color[1]), ("sunlight_color.z", s.sunlight_color[2]), ("sunlight_intensity", s.sunlight_intensity),
+                 ("sky_color.x", s.sky_color[0]), ("sky_color.y", s.sky_color[1]), ("sky_color.z", s.sky_color[2]), ("sky_intensity", s.sky_intensity)]:
+        assert f(v) == ref["settings." + k], k
+    cam = drt.Camera()
+    for k, v in [("exposure", cam.exposure), ("vfov_rad", cam.vfov_rad), ("defocus_angle", cam.defocus_angle), ("focus_dist", cam.focus_dist),
+                 ("m_movement_speed", cam.m_movement_speed)]:
+        assert f(v) == ref["camera." + k], k
+    for name in ("m_Position", "m_Forward_dir", "m_Up_dir", "m_Right_dir"):
+        for i, axis in enumerate("xyz"):
+            assert f(getattr(cam, name)[i]) == ref["camera.%s.%s" % (name, axis)], (name, axis)
+
+
+def test_cpp_wrapper_defaults_match_the_reference_headers(tmp_path):
+    """include/DustRayTracer.hpp: RendererSettings{} and Camera{} carry the reference's default member values."""
+    src = tmp_path / "defaults.cpp"
+    src.write_text(r"""
+#include <cstdio>
+#include <cstring>
+#include "DustRayTracer.hpp"
+static void kv(const char *k, long long v) { std::printf("%s=%lld\n", k, v); }
+static void kf(const char *k, float v) { unsigned u; std::memcpy(&u, &v, 4); kv(k, (long long)u); }
+int main() {
+    RendererSettings rs;
+    kv("settings.gamma_correction", rs.gamma_correction); kv("settings.tone_mapping", rs.tone_mapping); kv("settings.enableSunlight", rs.enableSunlight);
+    kv("settings.max_samples", rs.max_samples); kv("settings.ray_bounce_limit", rs.ray_bounce_limit);
+    kv("settings.RenderMode", (int)rs.RenderMode); kv("settings.DebugMode", (int)rs.DebugMode);
+    kf("settings.sunlight_dir.x", rs.sunlight_dir[0]); kf("settings.sunlight_dir.y", rs.sunlight_dir[1]);
+    kf("settings.sunlight_color.x", rs.sunlight_color.x); kf("settings.sunlight_color.y", rs.sunlight_color.y); kf("settings.sunlight_color.z", rs.sunlight_color.z);
+    kf("settings.sunlight_intensity", rs.sunlight_intensity);
+    kf("settings.sky_color.x", rs.sky_color.x); kf("settings.sky_color.y", rs.sky_color.y); kf("settings.sky_color.z", rs.sky_color.z);
+    kf("settings.sky_intensity", rs.sky_intensity);
+    Camera cam;
+    kf("camera.exposure", cam.exposure); kf("camera.vfov_rad", cam.vfov_rad); kf("camera.defocus_angle", cam.defocus_angle);
+    kf("camera.focus_dist", cam.focus_dist); kf("camera.m_movement_speed", cam.m_movement_speed);
+    kf("camera.m_Position.x", cam.m_Position.x); kf("camera.m_Position.y", cam.m_Position.y); kf("camera.m_Position.z", cam.m_Position.z);
+    kf("camera.m_Forward_dir.x", cam.m_Forward_dir.x); kf("camera.m_Forward_dir.y", cam.m_Forward_dir.y); kf("camera.m_Forward_dir.z", cam.m_Forward_dir.z);
+    kf("camera.m_Up_dir.x", cam.m_Up_dir.x); kf("camera.m_Up_dir.y", cam.m_Up_dir.y); kf("camera.m_Up_dir.z", cam.m_Up_dir.z);
+    kf("camera.m_Right_dir.x", cam.m_Right_dir.x); kf("camera.m_Right_dir.y", cam.m_Right_dir.y); kf("camera.m_Right_dir.z", cam.m_Right_dir.z);
+    kf("deg2rad_60", deg2rad(60));
+    return 0;
+}
+""")
+    exe = tmp_path / "defaults"
+    lib_dir = os.path.dirname(drt.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), str(src), "-L" + lib_dir, "-ldrt_hip",
+                    "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    ours = dict(line.split("=") for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split())
+    ref = _ref_layout()
+    assert len(ours) == 35
+    for k, v in ours.items():
+        assert int(v) == ref[k], (k, v, ref[k])
