@@ -266,6 +266,14 @@ def kat_intersect(rays6, tris9):
     return out, hit
 
 
+def kat_surface_area(boxes6, counts):
+    boxes6 = _f32(boxes6)
+    counts = np.ascontiguousarray(counts, np.int32)
+    out = np.zeros(len(counts), np.float32)
+    lib().o_kat_surface_area(_ptr(boxes6), _ptr(counts), C.c_int32(len(counts)), _ptr(out))
+    return out
+
+
 def kat_closest_hit(rays6, t, face_n3):
     data = np.ascontiguousarray(np.concatenate([_f32(rays6).reshape(-1, 6), _f32(t).reshape(-1, 1), _f32(face_n3).reshape(-1, 3)], axis=1))
     n = len(data)

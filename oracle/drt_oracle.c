@@ -923,6 +923,17 @@ void o_kat_intersect(const float *rays6, const float *tris9, int32_t n, float *o
     }
 }
 
+void o_kat_surface_area(const float *boxes6, const int32_t *counts, int32_t n, float *out)
+{
+    for (int32_t i = 0; i < n; i++) {
+        o_bvh_node node;
+        memset(&node, 0, sizeof node);
+        memcpy(node.bmin, &boxes6[6 * i], 12); memcpy(node.bmax, &boxes6[6 * i + 3], 12);
+        node.prim_count = counts[i];
+        out[i] = node_surface_area(&node);
+    }
+}
+
 void o_kat_closest_hit(const float *in10, int32_t n, float *out6, int32_t *front)
 {
     for (int32_t i = 0; i < n; i++) {

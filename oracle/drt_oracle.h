@@ -152,6 +152,8 @@ void o_kat_unit_disk(const uint32_t *seeds, int32_t n, float *out2, uint32_t *se
 void o_kat_slab(const float *rays6, const float *boxes6, int32_t n, float *out);
 /* Intersection.cu:4-36; tris9 = n x (v0,v1,v2); out4 = n x (t,U,V,W), hit[n] */
 void o_kat_intersect(const float *rays6, const float *tris9, int32_t n, float *out4, int32_t *hit);
+/* BVHNode.cuh:29-35 + Bounds.cu:4-10 (the SAH cost's surface area; 0 for an empty node) */
+void o_kat_surface_area(const float *boxes6, const int32_t *counts, int32_t n, float *out);
 /* Shaders/ClosestHit.cuh:4-28; in10 = n x (origin3, dir3, t, face_normal3); out6 = n x (position3, normal3), front[n] */
 void o_kat_closest_hit(const float *in10, int32_t n, float *out6, int32_t *front);
 /* Camera.cu:82-123; uv2 = n x (u,v); out6 = n x (origin3, dir3) */

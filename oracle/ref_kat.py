@@ -85,6 +85,18 @@ def layout():
     return {k: int(v) for k, v in (line.split("=") for line in _run("layout", b"").decode().splitlines() if line)}
 
 
+def centroid(tris9):
+    return np.frombuffer(_run("centroid", np.asarray(tris9, "<f4").reshape(-1, 9).tobytes()), "<f4").reshape(-1, 3).copy()
+
+
+def surfacearea(boxes6, counts):
+    rec = np.dtype([("box", "<f4", 6), ("count", "<i4")])
+    data = np.zeros(len(counts), rec)
+    data["box"] = np.asarray(boxes6, "<f4").reshape(-1, 6)
+    data["count"] = np.asarray(counts, "<i4")
+    return np.frombuffer(_run("surfacearea", data.tobytes()), "<f4").copy()
+
+
 def getray(cam, width, height, uv2, seeds):
     """cam = (exposure, vfov_rad, defocus_angle, focus_dist, pos3, fwd3)"""
     head = np.array([cam[0], cam[1], cam[2], cam[3], *cam[4], *cam[5], width, height], "<f4")

@@ -162,6 +162,21 @@ int main(int argc, char **argv)
         kf("camera.m_Up_dir.x", cam.m_Up_dir.x); kf("camera.m_Up_dir.y", cam.m_Up_dir.y); kf("camera.m_Up_dir.z", cam.m_Up_dir.z);
         kf("camera.m_Right_dir.x", cam.m_Right_dir.x); kf("camera.m_Right_dir.y", cam.m_Right_dir.y); kf("camera.m_Right_dir.z", cam.m_Right_dir.z);
         kf("deg2rad_60", deg2rad(60));
+    } else if (fn == "centroid") {                       // Triangle.cuh:9-12; in: n x (p0, p1, p2) -> out: n x centroid3
+        for (size_t i = 0; i + 9 <= in.size() / 4; i += 9) {
+            Vertex v0(make_float3(fin[i], fin[i + 1], fin[i + 2]), make_float3(0, 0, 0), make_float2(0, 0));
+            Vertex v1(make_float3(fin[i + 3], fin[i + 4], fin[i + 5]), make_float3(0, 0, 0), make_float2(0, 0));
+            Vertex v2(make_float3(fin[i + 6], fin[i + 7], fin[i + 8]), make_float3(0, 0, 0), make_float2(0, 0));
+            Triangle t(v0, v1, v2, make_float3(0, 0, 1), 0);
+            out.put3(t.centroid);
+        }
+    } else if (fn == "surfacearea") {                    // Bounds.cu:4-10 via BVHNode::getSurfaceArea (BVHNode.cuh:29-35); in: n x (min3, max3, i32 count) -> out: f32[n]
+        for (size_t i = 0; i + 7 <= in.size() / 4; i += 7) {
+            BVHNode node;
+            node.m_BoundingBox = Bounds3f(make_float3(fin[i], fin[i + 1], fin[i + 2]), make_float3(fin[i + 3], fin[i + 4], fin[i + 5]));
+            node.primitives_count = (int)uin[i + 6];
+            out.put(node.getSurfaceArea());
+        }
     } else if (fn == "getray") {
         // in: exposure, vfov_rad, defocus_angle, focus_dist, pos3, fwd3, width, height, then n x (u, v, u32 seed)
         Camera cam(make_float3(fin[4], fin[5], fin[6]));

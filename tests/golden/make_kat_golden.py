@@ -120,6 +120,9 @@ def main():
     out["slab"] = rk.slab(d["slab_rays"], d["slab_boxes"])
     out["isect_tuvw"], out["isect_hit"] = rk.intersect(d["isect_rays"], d["isect_tris"])
     out["ch_pos"], out["ch_normal"], out["ch_front"] = rk.closesthit(d["ch_rays"], d["ch_t"], d["ch_fn"])
+    out["centroid"] = rk.centroid(d["isect_tris"])
+    out["sa_count"] = (np.arange(len(d["slab_boxes"])) % 5).astype(np.int32)          # every 5th node is empty -> area 0
+    out["surfacearea"] = rk.surfacearea(d["slab_boxes"], out["sa_count"])
     c = d["cam_start"]
     out["cam_track"] = rk.cammove(c[0:3], c[3:6], c[6:9], c[9:12], c[12], d["cam_steps"])
     rays, rseeds = [], []

@@ -104,6 +104,27 @@ def test_closest_hit_matches_reference(kat_golden):
     assert 0.3 < front.mean() < 0.7
 
 
+def test_triangle_centroid_matches_reference(kat_golden):
+    """Triangle.cuh:11 (p0 + p1 + p2) / 3 -- the value the SAH builder bins by."""
+    g = kat_golden
+    p = g["isect_tris"].reshape(-1, 3, 3)
+    n = len(p)
+    z3, z2 = np.zeros((n * 3, 3), np.float32), np.zeros((n * 3, 2), np.float32)
+    tris = np.zeros(n, oracle.TRI_DTYPE)
+    pos = np.ascontiguousarray(p.reshape(-1, 3), np.float32)
+    nrm = np.ascontiguousarray(z3 + np.float32([0, 0, 1]), np.float32)
+    mat = np.zeros(n, np.int32)
+    oracle.lib().o_build_triangles(pos.ctypes.data, nrm.ctypes.data, z2.ctypes.data, mat.ctypes.data, n, tris.ctypes.data)
+    assert np.array_equal(bits(tris["centroid"]), bits(g["centroid"]))
+
+
+def test_node_surface_area_matches_reference(kat_golden):
+    g = kat_golden
+    sa = oracle.kat_surface_area(g["slab_boxes"], g["sa_count"])
+    assert np.array_equal(bits(sa), bits(g["surfacearea"]))
+    assert (sa[g["sa_count"] == 0] == 0).all() and (sa[g["sa_count"] > 0] != 0).any()
+
+
 def test_get_ray_matches_reference(kat_golden):
     g = kat_golden
     for k, cam in enumerate(g["cams"]):
