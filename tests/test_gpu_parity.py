@@ -422,3 +422,77 @@ def test_kernel_span_is_within_the_stream_event_time(renderer):
         span = renderer.kernelSpanMs()
     assert 0.0 < span <= ms * 1.02 + 0.01, (span, ms)
     assert span > 0.5 * ms, (span, ms)
+
+
+def _programmatic_pair(pos, nrm, uv, mat, materials, textures, leaf, bins):
+    """The same de-indexed geometry given to the product (drt_scene_set_geometry / add_material / add_texture) and to the oracle."""
+    sc = drt.Scene()
+    for tex in textures:
+        sc.addTexture(tex)
+    for alb, tex in materials:
+        sc.addMaterial(alb, tex)
+    sc.setGeometry(pos, nrm, uv, mat)
+    b = drt.BVHBuilder()
+    b.m_TargetLeafPrimitivesCount, b.m_BinCount = leaf, bins
+    b.buildIterative(sc)
+    n = len(mat)
+    tris = np.zeros(n, oracle.TRI_DTYPE)
+    a = [np.ascontiguousarray(x, np.float32) for x in (pos.reshape(-1, 3), nrm.reshape(-1, 3), uv.reshape(-1, 2))]
+    m = np.ascontiguousarray(mat, np.int32)
+    oracle.lib().o_build_triangles(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, m.ctypes.data, n, tris.ctypes.data)
+    osc = oracle.Scene(tris, materials, textures).build_bvh(leaf, bins)
+    return sc, osc
+
+
+def _render_both(renderer, sc, osc, pos, fwd, W, H, frames, **settings):
+    cam = drt.Camera(pos)
+    cam.m_Forward_dir = np.array(fwd, np.float32)
+    s, o = settings_pair(**settings)
+    renderer.m_RendererSettings = s
+    renderer.ResizeBuffer(W, H)
+    renderer.resetAccumulationBuffer()
+    renderer.RenderBatch(cam, sc, frames)
+    ref, _, _ = oracle.render(osc, oracle.default_camera(position=pos, forward=fwd), o, W, H, 1, frames)
+    return renderer.GetRenderTargetImage(), ref
+
+
+def test_edge_case_scenes_and_frame_sizes(renderer):
+    """Inputs at the edges: one triangle, a 1x1 and a 7x3 frame, a deep tree (stack > 16 levels, scene not in LDS), a long
+    path (32 bounces inside a closed box), RGB and RGBA textures given as arrays."""
+    rng = np.random.default_rng(5)
+    up = np.tile(np.float32([0, 0, 1]), (3, 1))
+    # (1) a single triangle, tiny frames
+    pos = np.float32([[[-1, -1, 0], [1, -1, 0], [0, 1, 0]]])
+    sc, osc = _programmatic_pair(pos, up[None], np.zeros((1, 3, 2), np.float32), [0], [((0.8, 0.3, 0.2), -1)], [], 20, 8)
+    assert len(sc.m_BVHNodes) == 1
+    for W, H in ((1, 1), (7, 3), (64, 1), (1, 64)):
+        img, ref = _render_both(renderer, sc, osc, (0.1, 0.0, 2.0), (0, 0, -1), W, H, 3, ray_bounce_limit=3)
+        compare(img, ref, "single triangle %dx%d" % (W, H))
+    # (2) triangle soup with small leaves: deep tree
+    n = 20000
+    c = rng.uniform(-4, 4, (n, 1, 3)).astype(np.float32)
+    pos = c + rng.uniform(-0.25, 0.25, (n, 3, 3)).astype(np.float32)
+    nrm = rng.normal(size=(n, 3, 3)).astype(np.float32)
+    uv = rng.uniform(-2, 3, (n, 3, 2)).astype(np.float32)
+    tex_rgb = rng.integers(0, 256, (19, 23, 3), dtype=np.uint8)
+    tex_rgba = rng.integers(0, 256, (8, 8, 4), dtype=np.uint8)
+    tex_rgba[..., 3] = np.where(rng.uniform(size=(8, 8)) < 0.5, 255, 40)
+    materials = [((0.9, 0.9, 0.9), -1), ((1.0, 1.0, 1.0), 0), ((0.7, 0.8, 0.9), 1)]
+    mat = rng.integers(0, 3, n).astype(np.int32)
+    sc, osc = _programmatic_pair(pos, nrm, uv, mat, materials, [tex_rgb, tex_rgba], 3, 8)
+    assert sc.bvh_depth > 16
+    img, ref = _render_both(renderer, sc, osc, (0.0, 0.5, 9.0), (0, -0.05, -1), 96, 54, 2, ray_bounce_limit=6)
+    compare(img, ref, "soup depth %d" % sc.bvh_depth)
+    assert "hbm-scene" in renderer.kernelInfo() and "stack=%d" % sc.bvh_depth in renderer.kernelInfo()
+    img, ref = _render_both(renderer, sc, osc, (0.0, 0.5, 9.0), (0, -0.05, -1), 96, 54, 2, ray_bounce_limit=6, enableSunlight=1)
+    compare(img, ref, "soup with sun shadows through cut-outs")
+    # (3) long paths: the closed cornell box with 32 bounces
+    sc, osc = make_pair("cornell_box")
+    cam, ocam = cameras("cornell_box")
+    s, o = settings_pair(ray_bounce_limit=32)
+    renderer.m_RendererSettings = s
+    renderer.ResizeBuffer(80, 45)
+    renderer.resetAccumulationBuffer()
+    renderer.RenderBatch(cam, sc, 2)
+    ref, _, _ = oracle.render(osc, ocam, o, 80, 45, 1, 2)
+    compare(renderer.GetRenderTargetImage(), ref, "32 bounces")
