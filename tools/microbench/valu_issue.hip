@@ -11,6 +11,10 @@ constexpr int kIters = 4096;
 // Each kernel: 16 independent chains x 8 ops per loop trip = 128 VALU ops per trip.
 template <int KIND>
 __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cycles, float seed, int n_iter) {
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    f2_t p[16];
+    for (int i = 0; i < 16; i++) { p[i].x = seed + i + threadIdx.x * 1e-3f; p[i].y = seed * 0.5f + i; }
+    const f2_t pc = { 1.0001f, 0.9999f };
     float a[16];
     unsigned u[16];
     for (int i = 0; i < 16; i++) { a[i] = seed + i + threadIdx.x * 1e-3f; u[i] = (unsigned)(seed * 977) + i * 7919u + threadIdx.x; }
@@ -38,6 +42,10 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cycles,
                 if (KIND == 15) { if (i == 0) a[0] = __builtin_fmaf(a[0], 1.0001f, 0.5f); }                // ONE dependent chain
                 if (KIND == 16) { if (i < 4) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f); }                  // four chains
                 if (KIND == 17) { if (i < 2) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.5f); }                  // two chains
+                if (KIND == 20) p[i] = p[i] * pc;                                       // v_pk_mul_f32
+                if (KIND == 21) p[i] = p[i] + pc;                                       // v_pk_add_f32
+                if (KIND == 22) p[i] = __builtin_elementwise_fma(p[i], pc, pc);         // v_pk_fma_f32
+                if (KIND == 23) { p[i].x = p[i].x * 1.0001f; p[i].y = p[i].y * 0.9999f; }   // two v_mul_f32 (same work as KIND 20)
                 if (KIND == 13) { bool c = a[i] < s; m ^= __builtin_amdgcn_ballot_w64(c); }   // v_cmp to SGPR + s_xor
                 if (KIND == 14) a[i] = (msk >> ((i + r) & 63) & 1) ? a[i] * 1.0001f : a[i];     // scalar-mask select
             }
@@ -45,7 +53,7 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cycles,
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     float acc = 0; unsigned ua = 0;
-    for (int i = 0; i < 16; i++) { acc += a[i]; ua ^= u[i]; }
+    for (int i = 0; i < 16; i++) { acc += a[i] + p[i].x + p[i].y; ua ^= u[i]; }
     out[blockIdx.x * 256 + threadIdx.x] = acc + (float)ua + (float)(m & 0xff);
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
@@ -86,6 +94,7 @@ int main() {
     run<8>("v_mul + v_min", 2); run<9>("v_mad_u32_u24", 1); run<10>("v_mul + IEEE sqrtf (instr count?)", 1); run<11>("v_mul + IEEE 1/x", 1);
     run<12>("v_cvt_f32_u32 + v_mul + v_sub", 3); run<13>("v_cmp->SGPR (+s_xor)", 1);
     printf("dependent chains (rate counts only the chain ops: 1/16, 4/16, 2/16 of the slots):\n");
+    run<20>("v_pk_mul_f32 (2 mul/lane)", 1); run<21>("v_pk_add_f32", 1); run<22>("v_pk_fma_f32", 1); run<23>("2 x v_mul_f32 (same work)", 2);
     run<15>("1 dependent v_fma chain (x16)", 1); run<17>("2 chains (x8)", 1); run<16>("4 chains (x4)", 1);
     return 0;
 }
