@@ -41,14 +41,24 @@ DRT_DEV f3 cross(f3 a, f3 b) {                                                  
 // tiny, huge).  They are NOT approximations: tests/test_gpu_parity.py compares each with the plain operator for EVERY one of
 // the 2^32 float bit patterns on the device (drt_debug_check_rcp / _sqrt, 0 mismatches required).
 DRT_DEV float exact_rcp(float x) {
-    const float ax = __builtin_fabsf(x);
-    if (!(ax >= 0x1p-100f && ax <= 0x1p100f)) return 1.0f / x;
     // v_rcp_f32 is within 1 ulp; one residual correction with exact FMAs lands on the correctly rounded quotient for every
     // float in the guarded range on gfx950 (tools/microbench/rcp_variants.hip tries the shorter and longer sequences, all 2^32
     // inputs each; the compiler's own expansion spends six FMAs plus the range scaling)
     const float r = __builtin_amdgcn_rcpf(x);
     const float rem = __builtin_fmaf(-x, r, 1.0f);
-    return __builtin_fmaf(rem, r, r);
+    float q = __builtin_fmaf(rem, r, r);
+    const float ax = __builtin_fabsf(x);
+    if (__builtin_expect(!(ax >= 0x1p-100f && ax <= 0x1p100f), 0)) q = 1.0f / x;
+    return q;
+}
+// For a divisor whose small values are thrown away by the caller anyway (the triangle test ignores the result when
+// |det| < 1e-6): only the upper end needs the plain operator.  Below 2^-100 the value returned is unspecified.
+DRT_DEV float exact_rcp_not_tiny(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    const float rem = __builtin_fmaf(-x, r, 1.0f);
+    float q = __builtin_fmaf(rem, r, r);
+    if (__builtin_expect(!(__builtin_fabsf(x) <= 0x1p100f), 0)) q = 1.0f / x;
+    return q;
 }
 DRT_DEV float exact_sqrt(float x) {
     if (!(x >= 0x1p-100f && x <= 0x1p100f)) return sqrtf(x);
@@ -168,7 +178,7 @@ DRT_DEV bool tri_intersect_flat(const Ray &ray, f3 v0, f3 e1, f3 e2, float &t, f
     f3 pvec = cross(ray.dir, e2);
     float det = dot(e1, pvec);
     bool ok = !((det > -DRT_TRIANGLE_EPSILON) & (det < DRT_TRIANGLE_EPSILON));
-    float inv_det = exact_rcp(det);
+    float inv_det = exact_rcp_not_tiny(det);          // !ok covers |det| < 1e-6: whatever comes back there is not used
     f3 tvec = ray.orig - v0;
     u = inv_det * dot(tvec, pvec);
     f3 qvec = cross(tvec, e1);
