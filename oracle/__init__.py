@@ -173,11 +173,25 @@ class Scene:
         return s
 
 
+def usable_cores():
+    """Threads worth starting: the affinity mask, capped by the cgroup CPU quota (more runnable threads than the quota
+    only get throttled: 256 threads under a 16-core quota run at a fraction of 16 threads' speed)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def render(scene, cam, settings, W, H, frame_first=1, n_frames=1, accum=None, threads=None,
            stripe_rows=1, rank=0, world=1, want_counters=False):
     """Returns (rgba[H,W,4] f32, accum[H,W,3] f32, Counters|None). Frame indices start at 1."""
     if threads is None:
-        threads = os.cpu_count() or 1
+        threads = usable_cores()
     if accum is None:
         accum = np.zeros((H, W, 3), np.float32)
     accum = np.ascontiguousarray(accum, np.float32)
