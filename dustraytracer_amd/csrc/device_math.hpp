@@ -141,6 +141,21 @@ DRT_DEV float slab_intersect(f3 bmin, f3 bmax, const Ray &ray) {
     return tenter;
 }
 
+// The same test for the closest-hit traversal, returned as "entry distance if the box is hit, +infinity if not".  Both
+// uses BVHTraversal.cuh:63-70 makes of the value survive that: `d >= 0 && d < closest` becomes `d < closest` (a hit's d
+// is >= 0 or NaN, and NaN fails either form; closest is finite), and the far-child-first order `d1 > d2` only matters
+// when both boxes are hit.  Two compare-to-mask instructions (4 cycles each on gfx950) fewer per box.
+DRT_DEV float slab_entry_or_inf(f3 bmin, f3 bmax, const Ray &ray) {
+    f3 t0 = (bmin - ray.orig) * ray.inv_dir;
+    f3 t1 = (bmax - ray.orig) * ray.inv_dir;
+    f3 tmin = mk3(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z));
+    f3 tmax = mk3(fmaxf(t1.x, t0.x), fmaxf(t1.y, t0.y), fmaxf(t1.z, t0.z));
+    float tenter = fmaxf(fmaxf(tmin.x, tmin.y), tmin.z);
+    float texit = fminf(fminf(tmax.x, tmax.y), tmax.z);
+    if (tenter < 0.0f) tenter = 0.0f;
+    return (tenter > texit || texit < 0) ? __builtin_inff() : tenter;
+}
+
 // ---- Kernel/Shaders/ClosestHit.cuh:13-24: hit position, and the face normal turned against the ray ----
 DRT_DEV bool closest_hit_frame(const Ray &ray, float t, f3 face_n, f3 &position, f3 &normal) {
     position = ray.orig + ray.dir * t;                                       // :13

@@ -426,6 +426,16 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
                     if (e.ref & kLeafBit) {
                         const LeafRange leaf = fetch_leaf(e.ref & ~kLeafBit);
                         cur = leaf.start; end = leaf.start + leaf.count;
+                    } else if (!GENERAL) {
+                        const ChildPair c = fetch_children(e.ref);
+                        const float d1 = slab_entry_or_inf(c.min1, c.max1, ray);     // +inf = missed (device_math.hpp)
+                        const float d2 = slab_entry_or_inf(c.min2, c.max2, ray);
+                        const bool first_is_1 = d1 > d2;          // farther child first; child 2 first on ties (:63-70)
+                        StackEntry ea, eb;                        // sort the two entries, then test each for the push
+                        ea.ref = first_is_1 ? c.ref1 : c.ref2; ea.dist = first_is_1 ? d1 : d2;
+                        eb.ref = first_is_1 ? c.ref2 : c.ref1; eb.dist = first_is_1 ? d2 : d1;
+                        if (ea.dist < hit_t) { stack[sp][tid] = ea; ++sp; }
+                        if (eb.dist < hit_t) { stack[sp][tid] = eb; ++sp; }
                     } else {
                         const ChildPair c = fetch_children(e.ref);
                         const float d1 = slab_intersect(c.min1, c.max1, ray);
