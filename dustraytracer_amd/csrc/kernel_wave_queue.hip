@@ -213,8 +213,12 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
         if (COUNT) c_rays++;
         if (sc.root_ref != kNoNode) {
             StackEntry e; e.ref = sc.root_ref; e.dist = slab_intersect(root_min, root_max, ray);
-            stack[0][tid] = e;
-            sp = 1;
+            // Lean: the pop-time test of BVHTraversal.cuh:38 (-1 < dist < FLT_MAX) can only ever fail for the root -- every
+            // other entry was pushed with 0 <= dist < closest -- so it is applied here, once per ray instead of once per pop.
+            if (GENERAL || (-1.0f < e.dist && e.dist < FLT_MAX)) {
+                stack[0][tid] = e;
+                sp = 1;
+            }
         }
     };
 
@@ -417,7 +421,9 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
                 --sp;
                 const StackEntry e = stack[sp][tid];
                 bool visit = true;
-                if (!(GENERAL && shadow)) {
+                if (!GENERAL) {
+                    visit = !(hit_t < e.dist);       // :41 (without a hit, hit_t = FLT_MAX > dist); :38 was applied to the root
+                } else if (!shadow) {
                     if (!(-1.0f < e.dist && e.dist < FLT_MAX)) visit = false;                   // :38
                     else if (hit_prim >= 0 && hit_t < e.dist) visit = false;                    // :41
                 }
