@@ -38,6 +38,9 @@ WORKLOADS = {
     "dense_monkey_1080p_16spp_d2": ("dense_monkey", 1920, 1080, 16, 2),      # configs[3]
     "room_4k_64spp_d16": ("room", 3840, 2160, 64, 16),                       # configs[4]
     "cs16_dust_1080p_8spp_d5": ("cs16_dust", 1920, 1080, 8, 5),              # large closed map: scene served from L2/HBM, not LDS
+    # the one configuration the reference shows a timing for (editor screenshot beforeBVHbuildrefactor_col.png: 843x460,
+    # 5 bounces, sample 50, 7.232 ms per frame index = 53.6 Msamples/s on the author's GTX 1650); alpha cut-out scene
+    "mc_transparency_843x460_50spp_d5": ("mc_transparency", 843, 460, 50, 5),
 }
 
 
@@ -275,6 +278,9 @@ def main():
                           "parallelism": "stripes%dx%d" % (STRIPE_ROWS, world) if world > 1 else "single",
                           "frames_in_flight": len(slots)},
                "roofline": roofline}
+        if args.workload == "mc_transparency_843x460_50spp_d5":
+            out["config"]["reference_screenshot"] = {"value": 53.6, "unit": "Msamples/s", "hardware": "GTX 1650 (presumed)",
+                                                     "source": "DustRayTracer/beforeBVHbuildrefactor_col.png", "ratio": round(value / 53.6, 1)}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(scene_key, W, H, depth, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -80,7 +80,8 @@ DRT_DEV int lane_rank(unsigned long long mask) {        // set bits below this l
 }
 
 // MODE 0: lean (NORMALMODE, tonemap+gamma on, no sunlight, no RGBA texture, no counters); 1: every setting honoured
-// at run time; 2: = 1 + exact work counters
+// at run time; 2: = 1 + exact work counters; 3: = lean + the alpha test of AnyHit.cuh on closest-hit candidates (scenes
+// with RGBA textures: the reference's cut-out foliage / fences)
 // stack_entries = traversal stack slots per lane (the BVH's depth): the LDS a workgroup takes is exactly what its tree needs
 #ifdef DRT_WAVES_PER_EU      // experiments only: force the register budget of that many waves per SIMD
 #define DRT_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(DRT_WAVES_PER_EU, DRT_WAVES_PER_EU)))
@@ -91,8 +92,9 @@ template <int MODE, bool LDS_SCENE>
 __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel(const SceneView sc, const FrameParams fp,
                                                               unsigned int *chunk_counter, uint32_t n_chunks, uint32_t tiles_x,
                                                               float4 *samples, uint32_t stack_entries) {
-    constexpr bool GENERAL = MODE >= 1;
+    constexpr bool GENERAL = MODE == 1 || MODE == 2;
     constexpr bool COUNT = MODE == 2;
+    constexpr bool ALPHA = MODE == 3;
     extern __shared__ uint4 lds_raw[];
     StackEntry(*stack)[kThreads] = reinterpret_cast<StackEntry(*)[kThreads]>(lds_raw);
     const int tid = threadIdx.x;
@@ -483,8 +485,9 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
                     float t0, u0, v0, t1, u1, v1;
                     const bool h0 = tri_intersect_flat(ray, ta.v0, ta.e1, ta.e2, t0, u0, v0);
                     const bool h1 = tri_intersect_flat(ray, tb.v0, tb.e1, tb.e2, t1, u1, v1) & two;
-                    if (h0 && t0 < hit_t) { hit_t = t0; hit_prim = i; hit_u = u0; hit_v = v0; }
-                    if (h1 && t1 < hit_t) { hit_t = t1; hit_prim = j; hit_u = u1; hit_v = v1; }
+                    // (with RGBA textures a candidate also has to pass the alpha test: BVHTraversal.cuh:50-52, AnyHit.cuh:8-28)
+                    if (h0 && t0 < hit_t && (!ALPHA || any_hit(sc, i, mk3(1.0f - u0 - v0, u0, v0)))) { hit_t = t0; hit_prim = i; hit_u = u0; hit_v = v0; }
+                    if (h1 && t1 < hit_t && (!ALPHA || any_hit(sc, j, mk3(1.0f - u1 - v1, u1, v1)))) { hit_t = t1; hit_prim = j; hit_u = u1; hit_v = v1; }
                 }
             } else if (cur < end) {
                 const int i = cur++;
@@ -607,10 +610,12 @@ hipError_t launch_mode(const SceneView &sc, const FrameParams &fp, int mode, boo
     if (lds_scene) {
         if (mode == 0) return launch_one<0, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
         if (mode == 1) return launch_one<1, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
+        if (mode == 3) return launch_one<3, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
         return launch_one<2, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
     }
     if (mode == 0) return launch_one<0, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
     if (mode == 1) return launch_one<1, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
+    if (mode == 3) return launch_one<3, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
     return launch_one<2, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
 }
 
@@ -638,7 +643,8 @@ hipError_t launch_wave_queue(const SceneView &sc, const FrameParams &fp, int bvh
                              unsigned int *chunk_counter, void *samples, int num_cus, hipStream_t stream, const char **kernel_name,
                              int *launch_shape) {
     if (fp.width == 0 || fp.local_rows == 0 || fp.n_frames == 0) return hipSuccess;
-    if (mode == 0 && (scene_has_alpha || fp.render_mode != 0 || fp.enable_sunlight || !fp.tone_mapping || !fp.gamma_correction)) mode = 1;
+    if (mode == 0 && (fp.render_mode != 0 || fp.enable_sunlight || !fp.tone_mapping || !fp.gamma_correction)) mode = 1;
+    if (mode == 0 && scene_has_alpha) mode = 3;
     // one slot per BVH level is all a depth-first walk that pushes both children can ever hold (BVHTraversal.cuh:20
     // fixes it at 64, which is also the reference's limit)
     if (bvh_depth > 64) return hipErrorInvalidValue;
@@ -650,8 +656,8 @@ hipError_t launch_wave_queue(const SceneView &sc, const FrameParams &fp, int bvh
     const size_t lds_bytes = stack_bytes + (lds_scene ? scene_bytes : 0);
     hipError_t e = hipMemsetAsync(chunk_counter, 0, sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
-    static const char *names[2][3] = { { "wave_queue<lean,hbm-scene>", "wave_queue<general,hbm-scene>", "wave_queue<counting,hbm-scene>" },
-                                       { "wave_queue<lean,lds-scene>", "wave_queue<general,lds-scene>", "wave_queue<counting,lds-scene>" } };
+    static const char *names[2][4] = { { "wave_queue<lean,hbm-scene>", "wave_queue<general,hbm-scene>", "wave_queue<counting,hbm-scene>", "wave_queue<lean+alpha,hbm-scene>" },
+                                       { "wave_queue<lean,lds-scene>", "wave_queue<general,lds-scene>", "wave_queue<counting,lds-scene>", "wave_queue<lean+alpha,lds-scene>" } };
     if (kernel_name) *kernel_name = names[lds_scene ? 1 : 0][mode];
     float4 *s4 = static_cast<float4 *>(samples);
     int blocks_per_cu = 0;

@@ -154,6 +154,18 @@ def test_alpha_cutout_changes_the_image(renderer):
     s, o = settings_pair(ray_bounce_limit=3)
     _, _, cnt = oracle.render(osc, ocam, o, 128, 128, 1, 1, want_counters=True)
     assert cnt.anyhit_alpha > 0, "pose does not exercise the alpha path"
+    for name, W, H in (("uv_texture_test", 128, 128), ("mc_transparency", 281, 153)):
+        sc, osc = make_pair(name)
+        cam, ocam = cameras(name)
+        s, o = settings_pair(ray_bounce_limit=SCENES[name][3])
+        renderer.m_RendererSettings = s
+        renderer.ResizeBuffer(W, H)
+        renderer.resetAccumulationBuffer()
+        renderer.RenderBatch(cam, sc, 3)
+        assert "lean+alpha" in renderer.kernelInfo()            # default settings + an RGBA texture in the scene
+        ref, _, cnt = oracle.render(osc, ocam, o, W, H, 1, 3, want_counters=True)
+        assert cnt.anyhit_alpha > 0
+        compare(renderer.GetRenderTargetImage(), ref, "%s alpha cut-outs, lean kernel" % name)
 
 
 def test_alpha_cutout_scene_with_sun_shadows(renderer):

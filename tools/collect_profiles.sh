@@ -26,7 +26,7 @@ python3 $R/tools/pmc_summary.py /tmp/p_sq1 /tmp/p_sq2 > $O/wave_queue_pmc_sq.txt
 # 5. phase statistics (counting build) and the other workloads
 python3 $R/tools/phase_stats.py cornell_box 8 > $O/phase_stats_cornell.txt
 python3 $R/tools/phase_stats.py cs16_dust 8 > $O/phase_stats_cs16_dust.txt
-for wl in suzanne_plane_1080p_8spp_d2 dense_monkey_1080p_16spp_d2 cs16_dust_1080p_8spp_d5 cornell_box_256_1spp_d4; do
+for wl in suzanne_plane_1080p_8spp_d2 dense_monkey_1080p_16spp_d2 cs16_dust_1080p_8spp_d5 cornell_box_256_1spp_d4 mc_transparency_843x460_50spp_d5; do
   python3 $R/bench.py --workload $wl --cpu-seconds 3 > $O/bench_$wl.json
 done
 python3 $R/bench.py --workload room_4k_64spp_d16 --cpu-seconds 3 --steps 3 --warmup 1 > $O/bench_room_4k_64spp_d16.json
