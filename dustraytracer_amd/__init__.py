@@ -218,6 +218,7 @@ _sig("drt_renderer_kernel_info", C.c_int, _P, C.c_char_p, C.c_size_t)
 _sig("drt_renderer_kernel_span", C.c_int, _P, C.POINTER(C.c_float))
 _sig("drt_assemble_shards", C.c_int, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P)
 _sig("drt_shard_rows", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
+_sig("drt_debug_decode_image", C.c_int, _P, C.c_size_t, _P, _P, C.c_size_t)
 _sig("drt_debug_kat", C.c_int, C.c_int32, C.c_int32, _P, C.c_size_t, _P, C.c_size_t, C.c_uint32, C.POINTER(_CameraPOD), C.c_uint32, C.c_uint32)
 _sig("drt_debug_hash_cycles", C.c_int, C.c_int32, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32))
 _sig("drt_debug_check_rcp", C.c_int, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
@@ -446,6 +447,16 @@ def debug_kat(which, inputs, cam=None, width=0, height=0, device=0):
     pod = cam._pod() if cam is not None else None
     _check(_lib.drt_debug_kat(device, which, a.ctypes.data, a.nbytes, out.ctypes.data, out.nbytes, len(a),
                               C.byref(pod) if pod is not None else None, width, height))
+    return out
+
+
+def debug_decode_image(file_bytes):
+    """The loader's image decoder (PNG / baseline JPEG) on a file held in memory -> uint8 [H, W, C]."""
+    buf = (C.c_uint8 * len(file_bytes)).from_buffer_copy(bytes(file_bytes))
+    info = _TexInfo()
+    _check(_lib.drt_debug_decode_image(buf, len(file_bytes), C.byref(info), None, 0))
+    out = np.zeros((info.height, info.width, info.components), np.uint8)
+    _check(_lib.drt_debug_decode_image(buf, len(file_bytes), C.byref(info), out.ctypes.data, out.size))
     return out
 
 

@@ -19,6 +19,7 @@
 #include "device_scene.hpp"
 #include "render_kernels.hpp"
 #include "scene_host.hpp"
+#include "png_decode.hpp"
 
 using namespace drt;
 
@@ -636,6 +637,22 @@ int drt_debug_check_rcp(int32_t device, uint64_t *mismatches, uint64_t *fast_pat
 }
 int drt_debug_check_sqrt(int32_t device, uint64_t *mismatches, uint64_t *fast_path_count) {
     return debug_check_exact(device, 1, mismatches, fast_path_count);
+}
+
+int drt_debug_decode_image(const uint8_t *file, size_t file_bytes, drt_texture_info *info, uint8_t *out, size_t cap) {
+    if (!file || !info) return fail(DRT_ERR_INVALID, "null argument");
+    try {
+        DecodedImage img;
+        if (looks_like_png(file, file_bytes)) img = decode_png(file, file_bytes);
+        else if (looks_like_jpeg(file, file_bytes)) img = decode_jpeg(file, file_bytes);
+        else return fail(DRT_ERR_UNSUPPORTED, "neither PNG nor JPEG");
+        info->width = img.width; info->height = img.height; info->components = img.components;
+        if (out) {
+            if (cap < img.texels.size()) return fail(DRT_ERR_INVALID, "destination too small");
+            std::memcpy(out, img.texels.data(), img.texels.size());
+        }
+    } catch (...) { return from_exception(); }
+    return DRT_OK;
 }
 
 int drt_debug_kat(int32_t device, int32_t which, const void *in, size_t in_bytes, void *out, size_t out_bytes, uint32_t n,

@@ -15,4 +15,8 @@ struct DecodedImage {
 bool looks_like_png(const uint8_t *data, size_t size);
 DecodedImage decode_png(const uint8_t *data, size_t size);   // throws std::runtime_error
 
+// jpeg_decode.cpp: baseline JPEG, output identical to the reference's decoder (vendored stb_image) byte for byte
+bool looks_like_jpeg(const uint8_t *data, size_t size);
+DecodedImage decode_jpeg(const uint8_t *data, size_t size);  // throws std::runtime_error
+
 }  // namespace drt

@@ -156,8 +156,10 @@ void HostScene::load_gltf(const char *path) {
         if (bv < 0 || (size_t)bv >= views.size()) throw UnsupportedError("image without bufferView (URI images) not supported");
         const BufferView &v = views[(size_t)bv];
         const uint8_t *p = buffers[(size_t)v.buffer].first + v.offset;
-        if (!looks_like_png(p, (size_t)v.length)) throw UnsupportedError("embedded image is not a PNG");
-        DecodedImage img = decode_png(p, (size_t)v.length);
+        DecodedImage img;
+        if (looks_like_png(p, (size_t)v.length)) img = decode_png(p, (size_t)v.length);
+        else if (looks_like_jpeg(p, (size_t)v.length)) img = decode_jpeg(p, (size_t)v.length);
+        else throw UnsupportedError("embedded image is neither PNG nor JPEG");
         HostTexture t;
         t.width = img.width; t.height = img.height; t.components = img.components;
         t.texels = std::move(img.texels);

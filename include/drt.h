@@ -198,6 +198,9 @@ int           drt_assemble_shards(const void *gathered, void *image, uint32_t wi
 /* Self-check of the kernels' reciprocal (device_math.hpp exact_rcp) against IEEE 1.0f/x over all 2^32 float bit patterns. */
 int           drt_debug_check_rcp(int32_t device, uint64_t *mismatches, uint64_t *fast_path_count);
 int           drt_debug_check_sqrt(int32_t device, uint64_t *mismatches, uint64_t *fast_path_count);   /* exact_sqrt vs sqrtf */
+/* Host: decode an image file held in memory (PNG, or baseline JPEG) exactly as the loader does for embedded glTF images
+ * (Scene.cu:93-114 -> Texture.cu:21-30: native channel count, row 0 first).  `out` may be NULL to query the size only. */
+int           drt_debug_decode_image(const uint8_t *file, size_t file_bytes, drt_texture_info *info, uint8_t *out, size_t cap);
 /* Device leaf functions on arrays, for known-answer tests against tests/golden/kat_ref.npz.
  * which: 0 unit vec (in u32 seed; out vec3,seed,tries), 1 unit sphere (same), 2 slab (in orig3,dir3,min3,max3; out f32),
  * 3 triangle (in orig3,dir3,v0,v1,v2; out t,U,V,W,hit), 4 camera ray (in u,v,seed; out orig3,dir3,seed; needs cam,width,height),

@@ -97,6 +97,15 @@ def surfacearea(boxes6, counts):
     return np.frombuffer(_run("surfacearea", data.tobytes()), "<f4").copy()
 
 
+def stbload(file_bytes):
+    """The reference's image decoder (vendored stb_image, as Texture.cu:23 calls it): HxWxC uint8, or None."""
+    raw = _run("stbload", bytes(file_bytes))
+    w, h, n = np.frombuffer(raw[:12], "<i4")
+    if w == 0:
+        return None
+    return np.frombuffer(raw[12:], np.uint8).reshape(h, w, n).copy()
+
+
 def getray(cam, width, height, uv2, seeds):
     """cam = (exposure, vfov_rad, defocus_angle, focus_dist, pos3, fwd3)"""
     head = np.array([cam[0], cam[1], cam[2], cam[3], *cam[4], *cam[5], width, height], "<f4")

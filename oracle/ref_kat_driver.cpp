@@ -25,6 +25,7 @@
 #include "Core/Scene/Mesh.cuh"
 #include "Core/Scene/RendererSettings.h"
 #include <cstddef>
+#include "stb_image.h"
 
 #include <cstdio>
 #include <cstring>
@@ -177,6 +178,12 @@ int main(int argc, char **argv)
             node.primitives_count = (int)uin[i + 6];
             out.put(node.getSurfaceArea());
         }
+    } else if (fn == "stbload") {                        // Texture.cu:21-30: in: an image file's bytes -> out: i32 w, h, comps, then the texels
+        int w = 0, h = 0, n = 0;
+        unsigned char *px = stbi_load_from_memory(in.data(), (int)in.size(), &w, &h, &n, 0);
+        out.put((int32_t)w); out.put((int32_t)h); out.put((int32_t)n);
+        if (px) out.b.insert(out.b.end(), px, px + (size_t)w * h * n);
+        else { out.b.clear(); out.put((int32_t)0); out.put((int32_t)0); out.put((int32_t)0); }
     } else if (fn == "getray") {
         // in: exposure, vfov_rad, defocus_angle, focus_dist, pos3, fwd3, width, height, then n x (u, v, u32 seed)
         Camera cam(make_float3(fin[4], fin[5], fin[6]));

@@ -21,6 +21,8 @@ SCENES = {
     # a full Counter-Strike map from the reference's models/source (11 167 triangles, 23 textured materials, closed
     # geometry: every path runs to the bounce limit): the large-scene case whose BVH and triangles do not fit in LDS
     "cs16_dust": ("cs16_dust.glb", (-11.4, 1.5, -3.85), (0.0, 0.0, 1.0), 5),
+    # the reference's sun-shadow test: a plane with a 2164x2152 baseline-JPEG texture under a cube (models/test)
+    "sunshadow_test": (os.path.join("test", "sunshadowTest.glb"), (0.0, 3.0, 7.0), (0.0, -0.35, -1.0), 3),
     "lightweight_rt": (os.path.join("test", "lightweightRTtest.glb"), (0.0, 1.8, 7.5), (0.0, -0.1, -1.0), 3),
 }
 

@@ -1,6 +1,8 @@
 """Host prep of the product (C++ glTF flattening, PNG decode, binned-SAH builder inside libdrt_hip.so)
 against the oracle's independent restatement (Python GLB reader + Pillow PNG + C builder).
 No GPU needed: these entry points never touch HIP.  Everything is bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -156,3 +158,56 @@ def test_camera_host_logic_matches_reference(kat_golden):
         got = np.concatenate([cam.m_Position, cam.m_Forward_dir, cam.m_Right_dir]).astype(np.float32)
         assert np.array_equal(bits(got), bits(g["cam_track"][k])), k
     assert np.linalg.norm(g["cam_track"][-1][:3] - c[0:3]) > 0.1
+
+
+def _jpeg_ref():
+    import json
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_ref.json")))
+
+
+def test_jpeg_decoders_match_the_reference_decoder():
+    """Baseline JPEG is lossy and its decoders differ (IDCT, chroma upsampling, colour conversion); texels feed the shading,
+    so both decoders here -- the product's C++ one and the oracle's numpy one -- must equal the reference's decoder (its
+    vendored stb_image, run from oracle/_ref/ref_kat to produce tests/golden/jpeg_ref.json) on every byte: 4:4:4, 4:2:2,
+    4:2:0, greyscale, restart intervals, optimised tables, sizes that are not MCU multiples, a 1x1 image."""
+    import glob
+    import hashlib
+    import dustraytracer_amd as drt
+    from oracle import jpeg_stb
+    ref = _jpeg_ref()
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg", "*.jpg")))
+    assert len(files) == 8
+    for f in files:
+        data = open(f, "rb").read()
+        want = ref[os.path.basename(f)]
+        for who, px in (("product", drt.debug_decode_image(data)), ("oracle", jpeg_stb.decode(data))):
+            assert list(px.shape) == want["shape"], (who, f)
+            assert px.reshape(-1)[:48].tolist() == want["head"], (who, f)
+            assert hashlib.sha256(px.tobytes()).hexdigest() == want["sha256"], (who, f)
+
+
+def test_reference_jpeg_textured_scene_loads_like_the_reference():
+    """models/test/sunshadowTest.glb (and three more of the reference's test scenes) embed one 2164x2152 baseline 4:2:0
+    JPEG: product loader and oracle loader both reproduce the reference decoder's 14 MB of texels exactly."""
+    import hashlib
+    import dustraytracer_amd as drt
+    want = _jpeg_ref()["sunshadowTest.glb#image0"]
+    sc = drt.Scene()
+    sc.loadGLTFmodel(scene_path("sunshadow_test"))
+    tex = sc.m_Textures
+    assert len(tex) == 1 and list(tex[0].shape) == want["shape"]
+    assert hashlib.sha256(tex[0].tobytes()).hexdigest() == want["sha256"]
+    osc = oracle.Scene.load_glb(scene_path("sunshadow_test"))
+    assert hashlib.sha256(osc.textures[0].tobytes()).hexdigest() == want["sha256"]
+
+
+def test_unsupported_jpeg_flavours_are_errors():
+    import io
+    import dustraytracer_amd as drt
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(np.zeros((16, 16, 3), np.uint8)).save(buf, "JPEG", progressive=True)
+    with pytest.raises(drt.DrtError):
+        drt.debug_decode_image(buf.getvalue())
+    with pytest.raises(drt.DrtError):
+        drt.debug_decode_image(buf.getvalue()[:100])
