@@ -56,6 +56,23 @@ def main():
         data = buf.getvalue()
         open(os.path.join(OUT, name + ".jpg"), "wb").write(data)
         ref[name + ".jpg"] = describe(rk.stbload(data))
+    # PNG is lossless, but the decoder still decides channel counts: palette (+tRNS) expansion, 16 -> 8 bits, 1-bit grey
+    png_dir = os.path.join(ROOT, "tests", "golden", "png")
+    os.makedirs(png_dir, exist_ok=True)
+    rng = np.random.default_rng(3)
+    pal = Image.fromarray(rng.integers(0, 256, (13, 17, 3), dtype=np.uint8)).quantize(16)
+    pngs = {"gray8": (Image.fromarray(rng.integers(0, 256, (13, 17), dtype=np.uint8)), {}),
+            "graya8": (Image.fromarray(rng.integers(0, 256, (13, 17, 2), dtype=np.uint8), "LA"), {}),
+            "rgb8": (Image.fromarray(rng.integers(0, 256, (13, 17, 3), dtype=np.uint8)), {}),
+            "rgba8": (Image.fromarray(rng.integers(0, 256, (13, 17, 4), dtype=np.uint8)), {}),
+            "gray16": (Image.fromarray(rng.integers(0, 65536, (13, 17), dtype=np.uint16)), {}),
+            "pal16": (pal, {}), "pal16_trns": (pal, dict(transparency=3)),
+            "bit1": (Image.fromarray(rng.integers(0, 2, (13, 17), dtype=np.uint8) * 255).convert("1"), {})}
+    for name, (im, kw) in pngs.items():
+        buf = io.BytesIO()
+        im.save(buf, "PNG", **kw)
+        open(os.path.join(png_dir, name + ".png"), "wb").write(buf.getvalue())
+        ref["png/" + name + ".png"] = describe(rk.stbload(buf.getvalue()))
     big = list(glb_images(os.path.join(ROOT, "models", "test", "sunshadowTest.glb")))[0]
     ref["sunshadowTest.glb#image0"] = describe(rk.stbload(big))
     json.dump(ref, open(os.path.join(ROOT, "tests", "golden", "jpeg_ref.json"), "w"), indent=1, sort_keys=True)
