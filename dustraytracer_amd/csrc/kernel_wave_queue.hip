@@ -79,9 +79,9 @@ DRT_DEV int lane_rank(unsigned long long mask) {        // set bits below this l
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
-// MODE 0: lean (NORMALMODE, tonemap+gamma on, no sunlight, no RGBA texture, no counters); 1: every setting honoured
+// MODE 0: lean (NORMALMODE, no sunlight, no RGBA texture, no counters); 1: every setting honoured
 // at run time; 2: = 1 + exact work counters; 3: = lean + the alpha test of AnyHit.cuh on closest-hit candidates (scenes
-// with RGBA textures: the reference's cut-out foliage / fences)
+// with RGBA textures: the reference's cut-out foliage / fences); 4: = lean + sunlight (a shadow ray per hit); 5: = 3 + 4
 // stack_entries = traversal stack slots per lane (the BVH's depth): the LDS a workgroup takes is exactly what its tree needs
 #ifdef DRT_WAVES_PER_EU      // experiments only: force the register budget of that many waves per SIMD
 #define DRT_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(DRT_WAVES_PER_EU, DRT_WAVES_PER_EU)))
@@ -94,7 +94,9 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
                                                               float4 *samples, uint32_t stack_entries) {
     constexpr bool GENERAL = MODE == 1 || MODE == 2;
     constexpr bool COUNT = MODE == 2;
-    constexpr bool ALPHA = MODE == 3;
+    constexpr bool ALPHA = MODE == 3 || MODE == 5;
+    constexpr bool SUN = MODE == 4 || MODE == 5;          // lean + the sun's shadow ray at every hit (RayGen.cuh:124-128)
+    constexpr bool SHADOWS = GENERAL || SUN;              // shadow traversals (RayTest, BVHTraversal.cuh:76-134) can occur
     extern __shared__ uint4 lds_raw[];
     StackEntry(*stack)[kThreads] = reinterpret_cast<StackEntry(*)[kThreads]>(lds_raw);
     const int tid = threadIdx.x;
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
 
     const int vote_node = fp.vote_node, vote_shade = fp.vote_shade, vote_dir = fp.vote_dir;
     const bool debug = GENERAL && fp.render_mode == 1;
-    const bool sun = GENERAL && fp.enable_sunlight && !debug;
+    const bool sun = SUN || (GENERAL && fp.enable_sunlight && !debug);
     const f3 root_min = ld3(sc.root_min), root_max = ld3(sc.root_max);
     const uint32_t local_pixels = fp.width * fp.local_rows;
 
@@ -186,10 +188,10 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
     float heat = 0;
     f3 light = mk3(0, 0, 0), throughput = mk3(1, 1, 1);
     // Origin and normal of the next bounce, kept from the shaded hit until its direction is drawn.  Only a sun shadow
-    // traversal (GENERAL) still needs the ray in between, so the lean kernel keeps them in the dead ray's registers.
+    // traversal still needs the ray in between, so the kernels without one keep them in the dead ray's registers.
     f3 bounce_origin_own = mk3(0, 0, 0), bounce_normal_own = mk3(0, 0, 0);
-    f3 &bounce_origin = GENERAL ? bounce_origin_own : ray.orig;
-    f3 &bounce_normal = GENERAL ? bounce_normal_own : ray.dir;
+    f3 &bounce_origin = SHADOWS ? bounce_origin_own : ray.orig;
+    f3 &bounce_normal = SHADOWS ? bounce_normal_own : ray.dir;
     f2 tex_uv; tex_uv.x = 0; tex_uv.y = 1;
     uint32_t seed = 0, slot = 0;     // slot: where this sample's colour goes in `samples`
     int bounce = 0;
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
             const bool in_s = !(cur < end) && !(sp > 0) && !(stage == kNeedDir && spec >= 0) && stage != kFinished;
             // Lean paths gather light only where they end (the sky term below), in the S run that also stores the
             // sample: the running sum is zero on entry, and resetting it here frees its registers between S runs.
-            if (!GENERAL) light = mk3(0, 0, 0);
+            if (!SHADOWS) light = mk3(0, 0, 0);
             // (a) a closest-hit traversal finished: RayGen.cuh:90-134
             if (in_s && stage == kTraceDone) {
                 seed += (uint32_t)bounce;                                                  // :91
@@ -326,8 +328,8 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
             // (c) path finished: post-process and park the sample's colour  RayGen.cuh:165-171
             if (in_s && stage == kPathDone) {
                 if (!debug || fp.debug_mode == 0) {
-                    if (!GENERAL || fp.tone_mapping) light = uncharted2_filmic(light, fp.exposure);
-                    if (!GENERAL || fp.gamma_correction) light = gamma_correction(light);
+                    if (fp.tone_mapping) light = uncharted2_filmic(light, fp.exposure);     // wave-uniform: a scalar branch
+                    if (fp.gamma_correction) light = gamma_correction(light);
                 }
                 samples[slot] = make_float4(light.x, light.y, light.z, 0.0f);
                 stage = kNeedSample;
@@ -424,7 +426,8 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
                 const StackEntry e = stack[sp][tid];
                 bool visit = true;
                 if (!GENERAL) {
-                    visit = !(hit_t < e.dist);       // :41 (without a hit, hit_t = FLT_MAX > dist); :38 was applied to the root
+                    // :41 (without a hit, hit_t = FLT_MAX > dist); :38 was applied to the root; a shadow traversal has no cull
+                    visit = !((SUN && shadow ? FLT_MAX : hit_t) < e.dist);
                 } else if (!shadow) {
                     if (!(-1.0f < e.dist && e.dist < FLT_MAX)) visit = false;                   // :38
                     else if (hit_prim >= 0 && hit_t < e.dist) visit = false;                    // :41
@@ -442,8 +445,9 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
                         StackEntry ea, eb;                        // sort the two entries, then test each for the push
                         ea.ref = first_is_1 ? c.ref1 : c.ref2; ea.dist = first_is_1 ? d1 : d2;
                         eb.ref = first_is_1 ? c.ref2 : c.ref1; eb.dist = first_is_1 ? d2 : d1;
-                        if (ea.dist < hit_t) { stack[sp][tid] = ea; ++sp; }
-                        if (eb.dist < hit_t) { stack[sp][tid] = eb; ++sp; }
+                        const float limit = SUN && shadow ? FLT_MAX : hit_t;        // RayTest pushes every box it hits (:122-129)
+                        if (ea.dist < limit) { stack[sp][tid] = ea; ++sp; }
+                        if (eb.dist < limit) { stack[sp][tid] = eb; ++sp; }
                     } else {
                         const ChildPair c = fetch_children(e.ref);
                         const float d1 = slab_intersect(c.min1, c.max1, ray);
@@ -486,6 +490,11 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
                     const bool h0 = tri_intersect_flat(ray, ta.v0, ta.e1, ta.e2, t0, u0, v0);
                     const bool h1 = tri_intersect_flat(ray, tb.v0, tb.e1, tb.e2, t1, u1, v1) & two;
                     // (with RGBA textures a candidate also has to pass the alpha test: BVHTraversal.cuh:50-52, AnyHit.cuh:8-28)
+                    if (SUN && shadow) {                                      // RayTest: any accepted hit ends the traversal (:105-117)
+                        const bool occ = (h0 && (!ALPHA || any_hit(sc, i, mk3(1.0f - u0 - v0, u0, v0)))) ||
+                                         (h1 && (!ALPHA || any_hit(sc, j, mk3(1.0f - u1 - v1, u1, v1))));
+                        if (occ) { occluded = true; cur = end = 0; sp = 0; }
+                    } else
                     if (h0 && t0 < hit_t && (!ALPHA || any_hit(sc, i, mk3(1.0f - u0 - v0, u0, v0)))) { hit_t = t0; hit_prim = i; hit_u = u0; hit_v = v0; }
                     if (h1 && t1 < hit_t && (!ALPHA || any_hit(sc, j, mk3(1.0f - u1 - v1, u1, v1)))) { hit_t = t1; hit_prim = j; hit_u = u1; hit_v = v1; }
                 }
@@ -505,7 +514,7 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
                 }
             }
             m_t = ballot(cur < end);
-            if (GENERAL) m_sp = ballot(sp > 0);
+            if (SHADOWS) m_sp = ballot(sp > 0);
             if (COUNT) d_time[0] += __builtin_amdgcn_s_memtime() - d_t0;
         }
     }
@@ -611,11 +620,15 @@ hipError_t launch_mode(const SceneView &sc, const FrameParams &fp, int mode, boo
         if (mode == 0) return launch_one<0, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
         if (mode == 1) return launch_one<1, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
         if (mode == 3) return launch_one<3, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
+        if (mode == 4) return launch_one<4, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
+        if (mode == 5) return launch_one<5, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
         return launch_one<2, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
     }
     if (mode == 0) return launch_one<0, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
     if (mode == 1) return launch_one<1, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
     if (mode == 3) return launch_one<3, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
+    if (mode == 4) return launch_one<4, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
+    if (mode == 5) return launch_one<5, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
     return launch_one<2, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
 }
 
@@ -643,8 +656,8 @@ hipError_t launch_wave_queue(const SceneView &sc, const FrameParams &fp, int bvh
                              unsigned int *chunk_counter, void *samples, int num_cus, hipStream_t stream, const char **kernel_name,
                              int *launch_shape) {
     if (fp.width == 0 || fp.local_rows == 0 || fp.n_frames == 0) return hipSuccess;
-    if (mode == 0 && (fp.render_mode != 0 || fp.enable_sunlight || !fp.tone_mapping || !fp.gamma_correction)) mode = 1;
-    if (mode == 0 && scene_has_alpha) mode = 3;
+    if (mode == 0 && fp.render_mode != 0) mode = 1;                                    // debug views: the general kernel
+    if (mode == 0) mode = fp.enable_sunlight ? (scene_has_alpha ? 5 : 4) : (scene_has_alpha ? 3 : 0);
     // one slot per BVH level is all a depth-first walk that pushes both children can ever hold (BVHTraversal.cuh:20
     // fixes it at 64, which is also the reference's limit)
     if (bvh_depth > 64) return hipErrorInvalidValue;
@@ -656,8 +669,10 @@ hipError_t launch_wave_queue(const SceneView &sc, const FrameParams &fp, int bvh
     const size_t lds_bytes = stack_bytes + (lds_scene ? scene_bytes : 0);
     hipError_t e = hipMemsetAsync(chunk_counter, 0, sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
-    static const char *names[2][4] = { { "wave_queue<lean,hbm-scene>", "wave_queue<general,hbm-scene>", "wave_queue<counting,hbm-scene>", "wave_queue<lean+alpha,hbm-scene>" },
-                                       { "wave_queue<lean,lds-scene>", "wave_queue<general,lds-scene>", "wave_queue<counting,lds-scene>", "wave_queue<lean+alpha,lds-scene>" } };
+    static const char *names[2][6] = { { "wave_queue<lean,hbm-scene>", "wave_queue<general,hbm-scene>", "wave_queue<counting,hbm-scene>", "wave_queue<lean+alpha,hbm-scene>",
+                                         "wave_queue<lean+sun,hbm-scene>", "wave_queue<lean+alpha+sun,hbm-scene>" },
+                                       { "wave_queue<lean,lds-scene>", "wave_queue<general,lds-scene>", "wave_queue<counting,lds-scene>", "wave_queue<lean+alpha,lds-scene>",
+                                         "wave_queue<lean+sun,lds-scene>", "wave_queue<lean+alpha+sun,lds-scene>" } };
     if (kernel_name) *kernel_name = names[lds_scene ? 1 : 0][mode];
     float4 *s4 = static_cast<float4 *>(samples);
     int blocks_per_cu = 0;

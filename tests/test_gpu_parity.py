@@ -179,7 +179,7 @@ def test_alpha_cutout_scene_with_sun_shadows(renderer):
         renderer.ResizeBuffer(168, 92)
         renderer.resetAccumulationBuffer()
         renderer.RenderBatch(cam, sc, 2)
-        assert "general" in renderer.kernelInfo()
+        assert ("lean+alpha+sun" if "enableSunlight" in kw else "general") in renderer.kernelInfo()
         ref, _, cnt = oracle.render(osc, ocam, o, 168, 92, 1, 2, want_counters=True)
         assert cnt.anyhit_alpha > 0
         compare(renderer.GetRenderTargetImage(), ref, "mc_transparency %r" % kw)

@@ -11,7 +11,8 @@ sc = drt.Scene(); sc.loadGLTFmodel(scene_path(name))
 b = drt.BVHBuilder(); b.m_TargetLeafPrimitivesCount, b.m_BinCount = 20, 8; b.buildIterative(sc)
 cam = drt.Camera(pos); cam.m_Forward_dir = np.array(fwd, np.float32)
 r = drt.Renderer(0)
-r.m_RendererSettings = drt.RendererSettings(ray_bounce_limit=depth, max_samples=spp + 1)
+extra = dict(enableSunlight=1) if os.environ.get("DRT_TW_SUN") == "1" else {}
+r.m_RendererSettings = drt.RendererSettings(ray_bounce_limit=depth, max_samples=spp + 1, **extra)
 r.ResizeBuffer(W, H)
 for k in range(2):
     r.resetAccumulationBuffer(); t0 = time.time(); ms = r.RenderBatch(cam, sc, spp); wall = time.time() - t0
