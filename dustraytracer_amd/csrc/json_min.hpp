@@ -34,6 +34,7 @@ struct JsonValue {
     bool is_number() const { return kind == Number; }
     long long as_int(long long dflt) const { return kind == Number ? (long long)num : dflt; }
     double as_double(double dflt) const { return kind == Number ? num : dflt; }
+    std::string as_string() const { return kind == String ? str : std::string(); }
 };
 
 class JsonParser {

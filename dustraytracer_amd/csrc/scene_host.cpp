@@ -90,6 +90,32 @@ static std::vector<uint8_t> read_file(const char *path) {
     return data;
 }
 
+// data:<mime>;base64,<payload>  (RFC 2397, base64 only -- what glTF exporters write)
+static std::vector<uint8_t> decode_data_uri(const std::string &uri) {
+    const size_t comma = uri.find(',');
+    if (comma == std::string::npos || uri.find(";base64") == std::string::npos || uri.find(";base64") > comma)
+        throw UnsupportedError("data: URI that is not base64");
+    std::vector<uint8_t> out;
+    out.reserve((uri.size() - comma) * 3 / 4);
+    uint32_t acc = 0;
+    int bits = 0;
+    for (size_t i = comma + 1; i < uri.size(); i++) {
+        const char c = uri[i];
+        int v;
+        if (c >= 'A' && c <= 'Z') v = c - 'A';
+        else if (c >= 'a' && c <= 'z') v = c - 'a' + 26;
+        else if (c >= '0' && c <= '9') v = c - '0' + 52;
+        else if (c == '+' || c == '-') v = 62;
+        else if (c == '/' || c == '_') v = 63;
+        else if (c == '=') break;
+        else continue;                                 // whitespace
+        acc = (acc << 6) | (uint32_t)v;
+        bits += 6;
+        if (bits >= 8) { bits -= 8; out.push_back((uint8_t)(acc >> bits)); }
+    }
+    return out;
+}
+
 static uint32_t le32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 
 struct BufferView { int64_t buffer = 0, offset = 0, length = 0; };
@@ -98,32 +124,47 @@ void HostScene::load_gltf(const char *path) {
     std::string spath(path ? path : "");
     size_t dot_at = spath.find_last_of('.');
     std::string ext = dot_at == std::string::npos ? "" : spath.substr(dot_at + 1);
-    if (ext != "glb")   // Scene.cu:38-41: the ASCII branch needs external .bin / image files relative to "../models/"
-        throw UnsupportedError("only binary glTF (.glb) is supported; no BASELINE scene uses the ASCII branch");
+    const bool is_binary = ext == "glb";             // Scene.cu:32-41: ".glb" = binary container, anything else = ASCII glTF
+    const size_t slash_at = spath.find_last_of("/\\");
+    const std::string base_dir = slash_at == std::string::npos ? std::string() : spath.substr(0, slash_at + 1);
 
     std::vector<uint8_t> blob = read_file(path);
-    if (blob.size() < 20 || std::memcmp(blob.data(), "glTF", 4) != 0) throw std::runtime_error("not a GLB file");
-    if (le32(blob.data() + 4) != 2) throw UnsupportedError("glTF container version != 2");
-    size_t total = std::min<size_t>(le32(blob.data() + 8), blob.size());
     const uint8_t *json_p = nullptr, *bin_p = nullptr;
     size_t json_n = 0, bin_n = 0;
-    for (size_t off = 12; off + 8 <= total;) {
-        uint32_t clen = le32(blob.data() + off), ctype = le32(blob.data() + off + 4);
-        if ((size_t)clen > total - off - 8) throw std::runtime_error("GLB chunk runs past end of file");
-        if (ctype == 0x4E4F534Au && !json_p) { json_p = blob.data() + off + 8; json_n = clen; }
-        else if (ctype == 0x004E4942u && !bin_p) { bin_p = blob.data() + off + 8; bin_n = clen; }
-        off += 8 + (size_t)clen + ((4 - clen % 4) % 4);
+    if (is_binary) {
+        if (blob.size() < 20 || std::memcmp(blob.data(), "glTF", 4) != 0) throw std::runtime_error("not a GLB file");
+        if (le32(blob.data() + 4) != 2) throw UnsupportedError("glTF container version != 2");
+        size_t total = std::min<size_t>(le32(blob.data() + 8), blob.size());
+        for (size_t off = 12; off + 8 <= total;) {
+            uint32_t clen = le32(blob.data() + off), ctype = le32(blob.data() + off + 4);
+            if ((size_t)clen > total - off - 8) throw std::runtime_error("GLB chunk runs past end of file");
+            if (ctype == 0x4E4F534Au && !json_p) { json_p = blob.data() + off + 8; json_n = clen; }
+            else if (ctype == 0x004E4942u && !bin_p) { bin_p = blob.data() + off + 8; bin_n = clen; }
+            off += 8 + (size_t)clen + ((4 - clen % 4) % 4);
+        }
+        if (!json_p) throw std::runtime_error("GLB has no JSON chunk");
+    } else {
+        json_p = blob.data(); json_n = blob.size();
     }
-    if (!json_p) throw std::runtime_error("GLB has no JSON chunk");
     JsonValue root = JsonParser((const char *)json_p, json_n).parse();
 
-    // buffers: the GLB-embedded buffer is the BIN chunk, truncated to byteLength
+    // buffers: the GLB-embedded buffer is the BIN chunk, truncated to byteLength; a buffer with a uri is a file next to the
+    // .gltf (what tinygltf's LoadASCIIFromFile resolves it against) or a base64 data: URI
     std::vector<std::pair<const uint8_t *, size_t>> buffers;
+    std::vector<std::vector<uint8_t>> owned;          // external buffers live here until the end of the load
     const JsonValue &jbuffers = root.at("buffers");
+    owned.reserve(jbuffers.size());
     for (size_t i = 0; i < jbuffers.size(); i++) {
         const JsonValue &b = jbuffers.at(i);
-        if (b.has("uri")) throw UnsupportedError("external / data-URI buffers are outside the supported subset");
         size_t len = (size_t)b.at("byteLength").as_int(0);
+        if (b.has("uri")) {
+            const std::string uri = b.at("uri").as_string();
+            owned.push_back(uri.compare(0, 5, "data:") == 0 ? decode_data_uri(uri) : read_file((base_dir + uri).c_str()));
+            if (len > owned.back().size()) throw std::runtime_error("buffer.byteLength exceeds the external buffer");
+            buffers.emplace_back(owned.back().data(), len);
+            continue;
+        }
+        if (!is_binary) throw std::runtime_error("ASCII glTF buffer without a uri");
         if (len > bin_n) throw std::runtime_error("buffer.byteLength exceeds the BIN chunk");
         buffers.emplace_back(bin_p, len);
     }
@@ -152,14 +193,30 @@ void HostScene::load_gltf(const char *path) {
     // loadTextures (Scene.cu:88-117): one texture per IMAGE, decoded from its bufferView
     const JsonValue &jimages = root.at("images");
     for (size_t i = 0; i < jimages.size(); i++) {
-        int64_t bv = jimages.at(i).at("bufferView").as_int(-1);
-        if (bv < 0 || (size_t)bv >= views.size()) throw UnsupportedError("image without bufferView (URI images) not supported");
-        const BufferView &v = views[(size_t)bv];
-        const uint8_t *p = buffers[(size_t)v.buffer].first + v.offset;
+        std::vector<uint8_t> file;                    // ASCII branch: the image is a file
+        const uint8_t *p = nullptr;
+        size_t n = 0;
+        if (is_binary) {                              // Scene.cu:100-104
+            int64_t bv = jimages.at(i).at("bufferView").as_int(-1);
+            if (bv < 0 || (size_t)bv >= views.size()) throw UnsupportedError("GLB image without bufferView (the reference indexes bufferViews[-1] here)");
+            const BufferView &v = views[(size_t)bv];
+            p = buffers[(size_t)v.buffer].first + v.offset; n = (size_t)v.length;
+        } else {
+            // Scene.cu:90,111: the reference opens "../models/" + uri relative to the process's working directory.  That
+            // path is tried first; a file next to the .gltf (where the uri actually points) is the fallback.
+            const std::string uri = jimages.at(i).at("uri").as_string();
+            if (uri.empty()) throw UnsupportedError("ASCII glTF image without a uri");
+            if (uri.compare(0, 5, "data:") == 0) file = decode_data_uri(uri);
+            else {
+                try { file = read_file(("../models/" + uri).c_str()); }
+                catch (const IoError &) { file = read_file((base_dir + uri).c_str()); }
+            }
+            p = file.data(); n = file.size();
+        }
         DecodedImage img;
-        if (looks_like_png(p, (size_t)v.length)) img = decode_png(p, (size_t)v.length);
-        else if (looks_like_jpeg(p, (size_t)v.length)) img = decode_jpeg(p, (size_t)v.length);
-        else throw UnsupportedError("embedded image is neither PNG nor JPEG");
+        if (looks_like_png(p, n)) img = decode_png(p, n);
+        else if (looks_like_jpeg(p, n)) img = decode_jpeg(p, n);
+        else throw UnsupportedError("image is neither PNG nor JPEG");
         HostTexture t;
         t.width = img.width; t.height = img.height; t.components = img.components;
         t.texels = std::move(img.texels);

@@ -26,6 +26,8 @@ import io
 import json
 import struct
 
+import os
+
 import numpy as np
 
 
@@ -91,20 +93,42 @@ def _decode_image(data):
 def flatten(path):
     """Returns dict(pos[n*3,3] f32, nrm[n*3,3] f32, uv[n*3,2] f32, mat[n] i32,
     materials=[(albedo3, tex_index)], textures=[uint8 HxWxC], meshes=[(offset, count)])."""
-    gltf, bin_chunk = read_glb(path)
+    is_binary = path.rsplit(".", 1)[-1] == "glb"                  # Scene.cu:32-41
+    base_dir = os.path.dirname(os.path.abspath(path))
+    if is_binary:
+        gltf, bin_chunk = read_glb(path)
+    else:
+        with open(path, "rb") as f:
+            gltf, bin_chunk = json.loads(f.read().decode("utf-8")), b""
     accessors = gltf.get("accessors", [])
     views = gltf.get("bufferViews", [])
+
+    def from_uri(uri, dirs):
+        if uri.startswith("data:"):
+            import base64
+            return base64.b64decode(uri.split(",", 1)[1])
+        for d in dirs:
+            try:
+                with open(os.path.join(d, uri), "rb") as f:
+                    return f.read()
+            except OSError:
+                continue
+        raise FileNotFoundError(uri)
+
     buffers = []
     for b in gltf.get("buffers", []):
-        if "uri" in b:
-            raise ValueError("external buffers are not used by any fixture")
-        buffers.append(bin_chunk[: b["byteLength"]])
+        data = from_uri(b["uri"], [base_dir]) if "uri" in b else bin_chunk     # tinygltf resolves buffers next to the file
+        buffers.append(data[: b["byteLength"]])
 
     textures = []
     for img in gltf.get("images", []):
-        bv = views[img["bufferView"]]
-        start = bv.get("byteOffset", 0)
-        textures.append(_decode_image(buffers[bv["buffer"]][start: start + bv["byteLength"]]))
+        if is_binary:                                                          # Scene.cu:100-104
+            bv = views[img["bufferView"]]
+            start = bv.get("byteOffset", 0)
+            data = buffers[bv["buffer"]][start: start + bv["byteLength"]]
+        else:                                                                  # Scene.cu:90,111: "../models/" + uri from the cwd
+            data = from_uri(img["uri"], [os.path.join("..", "models"), base_dir])
+        textures.append(_decode_image(data))
 
     materials = []
     for m in gltf.get("materials", []):

@@ -23,6 +23,11 @@ SCENES = {
     "cs16_dust": ("cs16_dust.glb", (-11.4, 1.5, -3.85), (0.0, 0.0, 1.0), 5),
     # the reference's sun-shadow test: a plane with a 2164x2152 baseline-JPEG texture under a cube (models/test)
     "sunshadow_test": (os.path.join("test", "sunshadowTest.glb"), (0.0, 3.0, 7.0), (0.0, -0.35, -1.0), 3),
+    # the ASCII glTF branch (Scene.cu:38-41): external .bin, texture file named by uri.  cornell_box.gltf is a 36-triangle
+    # variant of the box with a ceiling light mesh and a different texture; suzanne_plane.gltf has node TRS (ignored)
+    "cornell_box_gltf": ("cornell_box.gltf", (3.6, 1.25, 0.0), (-1.0, 0.0, 0.0), 4),
+    "uv_texture_gltf": ("UVtextureTest.gltf", (0.0, 1.0, 4.0), (0.0, -0.1, -1.0), 3),
+    "suzanne_plane_gltf": ("suzanne_plane.gltf", (0.0, 1.2, 4.5), (0.0, -0.15, -1.0), 2),
     "lightweight_rt": (os.path.join("test", "lightweightRTtest.glb"), (0.0, 1.8, 7.5), (0.0, -0.1, -1.0), 3),
 }
 

@@ -65,7 +65,8 @@ def renderer():
                                              ("room", 128, 72, 2), ("uv_texture_test", 128, 128, 2),
                                              ("bvh_split_test", 96, 64, 2), ("multi_material", 96, 64, 2),
                                              ("mc_transparency", 211, 115, 3), ("lightweight_rt", 128, 72, 2),
-                                             ("cs16_dust", 160, 90, 2), ("sunshadow_test", 160, 90, 2)])
+                                             ("cs16_dust", 160, 90, 2), ("sunshadow_test", 160, 90, 2),
+                                             ("cornell_box_gltf", 160, 90, 2), ("uv_texture_gltf", 96, 96, 2)])
 def test_image_matches_oracle(renderer, name, W, H, frames):
     sc, osc = make_pair(name)
     depth = 4 if (name, W) == ("cornell_box", 256) else SCENES[name][3]      # C1 = 256x256 1spp depth 4

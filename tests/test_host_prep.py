@@ -124,7 +124,7 @@ def test_loader_errors_are_reported_not_fatal(tmp_path):
     assert e.value.code == drt.ERR_PARSE
     with pytest.raises(drt.DrtError) as e:
         sc.loadGLTFmodel(str(tmp_path / "scene.gltf"))
-    assert e.value.code == drt.ERR_UNSUPPORTED
+    assert e.value.code == drt.ERR_IO
     # a scene that failed to load keeps the handle usable
     sc.loadGLTFmodel(scene_path("room"))
     assert len(sc.m_PrimitivesBuffer) == 330
@@ -232,3 +232,50 @@ def test_unsupported_jpeg_flavours_are_errors():
         drt.debug_decode_image(buf.getvalue())
     with pytest.raises(drt.DrtError):
         drt.debug_decode_image(buf.getvalue()[:100])
+
+
+def test_ascii_gltf_with_data_uris_and_external_files(tmp_path):
+    """The ASCII branch (Scene.cu:38-41): buffers from a file next to the .gltf or from a base64 data: URI, images from the
+    uri (the reference's "../models/" + uri first, then next to the file).  The same geometry packed three ways must load
+    to the same triangles as the .glb."""
+    import base64
+    import json
+    import shutil
+    import struct
+    src = scene_path("uv_texture_test")                         # a GLB with one PNG
+    blob = open(src, "rb").read()
+    jlen = struct.unpack_from("<I", blob, 12)[0]
+    gltf = json.loads(blob[20:20 + jlen])
+    bin_chunk = blob[20 + jlen + 8:]
+    want = drt.Scene()
+    want.loadGLTFmodel(src)
+    # external files: every image's bufferView becomes a .png file, the buffer a .bin file
+    def image_bytes(k):
+        bv = gltf["bufferViews"][gltf["images"][k]["bufferView"]]
+        return bin_chunk[bv.get("byteOffset", 0): bv.get("byteOffset", 0) + bv["byteLength"]]
+    n_img = len(gltf["images"])
+    g = json.loads(json.dumps(gltf))
+    (tmp_path / "tex").mkdir()
+    for k in range(n_img):
+        g["images"][k] = {"uri": "tex/picture%d.png" % k}
+        (tmp_path / "tex" / ("picture%d.png" % k)).write_bytes(image_bytes(k))
+    g["buffers"][0]["uri"] = "geometry.bin"
+    (tmp_path / "geometry.bin").write_bytes(bin_chunk[: gltf["buffers"][0]["byteLength"]])
+    (tmp_path / "a.gltf").write_text(json.dumps(g))
+    # data URIs for both
+    g2 = json.loads(json.dumps(g))
+    for k in range(n_img):
+        g2["images"][k] = {"uri": "data:image/png;base64," + base64.b64encode(image_bytes(k)).decode()}
+    g2["buffers"][0]["uri"] = "data:application/octet-stream;base64," + base64.b64encode(bin_chunk[: gltf["buffers"][0]["byteLength"]]).decode()
+    (tmp_path / "b.gltf").write_text(json.dumps(g2))
+    for name in ("a.gltf", "b.gltf"):
+        sc = drt.Scene()
+        sc.loadGLTFmodel(str(tmp_path / name))
+        assert np.array_equal(sc.m_PrimitivesBuffer.view(np.uint8), want.m_PrimitivesBuffer.view(np.uint8)), name
+        assert all(np.array_equal(a, b) for a, b in zip(sc.m_Textures, want.m_Textures)) and len(sc.m_Textures) == n_img, name
+        osc = oracle.Scene.load_glb(str(tmp_path / name))
+        assert all(np.array_equal(a, b) for a, b in zip(osc.textures, want.m_Textures)) and len(osc.tris) == len(want.m_PrimitivesBuffer)
+    shutil.rmtree(tmp_path / "tex")
+    with pytest.raises(drt.DrtError) as e:                      # the image file is gone
+        drt.Scene().loadGLTFmodel(str(tmp_path / "a.gltf"))
+    assert e.value.code == drt.ERR_IO
