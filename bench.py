@@ -132,11 +132,14 @@ def main():
     # Rehearsal switch for a 1-GPU box (RCCL refuses two ranks on one device): every rank renders on device 0 and the
     # gather goes through gloo on host copies.  Never set by the driver; the JSON line says so when it is used.
     rehearsal = os.environ.get("DRT_BENCH_REHEARSAL") == "1"
+    # DRT_BENCH_FORCE_DIST=1 (under torch.distributed.run --nproc-per-node 1): take the multi-GPU code path -- process group on
+    # nccl (= RCCL), dist.gather, assemble kernel, barrier, all_reduce -- with a world of one rank, on a one-GPU box
+    dist_on = world > 1 or (os.environ.get("DRT_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if dist_on:
         if rehearsal:
             dist.init_process_group(backend="gloo")
         else:
@@ -171,7 +174,7 @@ def main():
             self.stream = torch.cuda.Stream(device=dev)
             self.r.setStream(self.stream.cuda_stream)
             self.gathered = self.image = self.host = None
-            if world > 1 and rank == 0:
+            if dist_on and rank == 0:
                 self.gathered = torch.empty((world, padded, W, 4), dtype=torch.float32, device=dev)
                 self.image = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
             self.busy = False
@@ -194,7 +197,7 @@ def main():
             slot.r.resetAccumulationBuffer()
             slot.r.RenderBatchAsync(cam, scene, spp)
             slot.busy = True
-            if world > 1:
+            if dist_on:
                 if rehearsal:
                     host = torch.empty((world,) + tuple(slot.rgba.shape), dtype=torch.float32) if rank == 0 else None
                     gather_shards(slot.rgba.cpu(), host, rank)
@@ -212,7 +215,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -241,7 +244,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     image = slots[(args.steps - 1) % len(slots)].image
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -284,7 +287,7 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(scene_key, W, H, depth, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         if rank == 0 and os.environ.get("DRT_BENCH_CHECK") == "1":
             # self-check of the sharded path: the assembled image must equal an unsharded render bit for bit
             torch.cuda.synchronize()
