@@ -182,6 +182,7 @@ _sig("drt_camera_move", None, _P, _P, _P, _P, _P, C.c_float, C.c_float)
 _sig("drt_scene_create", _P)
 _sig("drt_scene_destroy", None, _P)
 _sig("drt_scene_load_gltf", C.c_int, _P, C.c_char_p)
+_sig("drt_scene_load_gltf_ex", C.c_int, _P, C.c_char_p, C.c_uint32)
 _sig("drt_scene_set_geometry", C.c_int, _P, _P, _P, _P, _P, C.c_int32)
 _sig("drt_scene_add_material", C.c_int, _P, C.POINTER(C.c_float), C.c_int32)
 _sig("drt_scene_add_texture", C.c_int, _P, _P, C.c_int32, C.c_int32, C.c_int32)
@@ -263,8 +264,10 @@ class Scene:
         if h:
             _lib.drt_scene_destroy(h)
 
-    def loadGLTFmodel(self, filepath):
-        _check(_lib.drt_scene_load_gltf(self._h, os.fsencode(filepath)))
+    def loadGLTFmodel(self, filepath, strict=False):
+        """strict=False: the reference's reading of the file (Scene.cu, quirks included); True: the glTF 2.0 specification's
+        (node transforms and hierarchy, accessor offsets / strides / component types, u8/u16/u32 or no indices, ...)."""
+        _check(_lib.drt_scene_load_gltf_ex(self._h, os.fsencode(filepath), 1 if strict else 0))
         return True
 
     def setGeometry(self, positions, normals, uvs, material_ids):

@@ -168,6 +168,12 @@ int drt_scene_load_gltf(drt_scene *s, const char *path) {
     try { s->host.load_gltf(path); return DRT_OK; } catch (...) { return from_exception(); }
 }
 
+int drt_scene_load_gltf_ex(drt_scene *s, const char *path, uint32_t flags) {
+    if (!s || !path) return fail(DRT_ERR_INVALID, "null argument");
+    if (flags & ~DRT_LOAD_STRICT) return fail(DRT_ERR_INVALID, "unknown load flag");
+    try { s->host.load_gltf(path, (flags & DRT_LOAD_STRICT) != 0); return DRT_OK; } catch (...) { return from_exception(); }
+}
+
 int drt_scene_set_geometry(drt_scene *s, const float *positions, const float *normals, const float *uvs,
                            const int32_t *material_ids, int32_t n_tris) {
     if (!s || n_tris < 0 || (n_tris > 0 && (!positions || !normals || !uvs || !material_ids)))

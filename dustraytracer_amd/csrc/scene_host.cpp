@@ -118,9 +118,211 @@ static std::vector<uint8_t> decode_data_uri(const std::string &uri) {
 
 static uint32_t le32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 
-struct BufferView { int64_t buffer = 0, offset = 0, length = 0; };
+struct BufferView { int64_t buffer = 0, offset = 0, length = 0, stride = 0; };
 
-void HostScene::load_gltf(const char *path) {
+// ---------------------------------------------------------------------------------------------
+// Opt-in: geometry as the glTF 2.0 specification defines it (drt_scene_load_gltf_ex, DRT_LOAD_STRICT).  What the
+// reference's loader assumes away (Scene.cu:120-200) is honoured here: the scene graph and node transforms, accessor
+// byteOffset / componentType / bufferView.byteStride, u8 / u16 / u32 or absent indices, nodes without a mesh, a mesh used
+// by several nodes, missing NORMAL / TEXCOORD_0 / material.  Triangle assembly (centroid, face normal turned towards the
+// averaged vertex normal) is the reference's, so a file that satisfies the reference's assumptions loads identically.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Accessor {
+    const uint8_t *base = nullptr;
+    size_t stride = 0, count = 0;
+    int component = 0, width = 0;
+    bool normalized = false;
+    double get(size_t i, int k) const {
+        const uint8_t *p = base + i * stride;
+        switch (component) {
+        case 5126: { float v; std::memcpy(&v, p + 4 * k, 4); return v; }
+        case 5121: { uint8_t v = p[k]; return normalized ? v / 255.0 : v; }
+        case 5123: { uint16_t v; std::memcpy(&v, p + 2 * k, 2); return normalized ? v / 65535.0 : v; }
+        case 5125: { uint32_t v; std::memcpy(&v, p + 4 * k, 4); return v; }
+        case 5120: { int8_t v; std::memcpy(&v, p + k, 1); return normalized ? std::max(v / 127.0, -1.0) : v; }
+        case 5122: { int16_t v; std::memcpy(&v, p + 2 * k, 2); return normalized ? std::max(v / 32767.0, -1.0) : v; }
+        default: return 0;
+        }
+    }
+};
+
+Accessor open_accessor(const JsonValue &root, const std::vector<std::pair<const uint8_t *, size_t>> &buffers,
+                       const std::vector<BufferView> &views, int64_t index, int want_width) {
+    const JsonValue &jacc = root.at("accessors");
+    if (index < 0 || (size_t)index >= jacc.size()) throw std::runtime_error("accessor index out of range");
+    const JsonValue &a = jacc.at((size_t)index);
+    if (a.has("sparse")) throw UnsupportedError("sparse accessors");
+    const int64_t bv = a.at("bufferView").as_int(-1);
+    if (bv < 0 || (size_t)bv >= views.size()) throw std::runtime_error("accessor without bufferView");
+    const std::string type = a.at("type").as_string();
+    Accessor acc;
+    acc.width = type == "SCALAR" ? 1 : type == "VEC2" ? 2 : type == "VEC3" ? 3 : type == "VEC4" ? 4 : 0;
+    if (acc.width != want_width) throw std::runtime_error("accessor type does not fit its use");
+    acc.component = (int)a.at("componentType").as_int(0);
+    const size_t csize = acc.component == 5126 || acc.component == 5125 ? 4 : acc.component == 5123 || acc.component == 5122 ? 2
+                       : acc.component == 5121 || acc.component == 5120 ? 1 : 0;
+    if (!csize) throw std::runtime_error("unknown accessor componentType");
+    acc.normalized = a.at("normalized").kind == JsonValue::Bool && a.at("normalized").b;
+    acc.count = (size_t)a.at("count").as_int(0);
+    const BufferView &v = views[(size_t)bv];
+    acc.stride = v.stride > 0 ? (size_t)v.stride : csize * (size_t)acc.width;
+    const size_t offset = (size_t)a.at("byteOffset").as_int(0);
+    if (acc.count && offset + acc.stride * (acc.count - 1) + csize * (size_t)acc.width > (size_t)v.length)
+        throw std::runtime_error("accessor runs past its bufferView");
+    acc.base = buffers[(size_t)v.buffer].first + v.offset + offset;
+    return acc;
+}
+
+struct Mat4 { double m[16]; };      // column-major, as glTF stores it
+Mat4 identity() { Mat4 r{}; r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1; return r; }
+Mat4 mul(const Mat4 &a, const Mat4 &b) {
+    Mat4 r{};
+    for (int c = 0; c < 4; c++)
+        for (int row = 0; row < 4; row++) {
+            double s = 0;
+            for (int k = 0; k < 4; k++) s += a.m[k * 4 + row] * b.m[c * 4 + k];
+            r.m[c * 4 + row] = s;
+        }
+    return r;
+}
+Mat4 local_matrix(const JsonValue &node) {
+    if (node.has("matrix") && node.at("matrix").size() == 16) {
+        Mat4 r;
+        for (int i = 0; i < 16; i++) r.m[i] = node.at("matrix").at((size_t)i).as_double(0);
+        return r;
+    }
+    double t[3] = { 0, 0, 0 }, q[4] = { 0, 0, 0, 1 }, sc[3] = { 1, 1, 1 };
+    if (node.at("translation").size() == 3) for (int i = 0; i < 3; i++) t[i] = node.at("translation").at((size_t)i).as_double(0);
+    if (node.at("rotation").size() == 4) for (int i = 0; i < 4; i++) q[i] = node.at("rotation").at((size_t)i).as_double(i == 3);
+    if (node.at("scale").size() == 3) for (int i = 0; i < 3; i++) sc[i] = node.at("scale").at((size_t)i).as_double(1);
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    Mat4 r = identity();
+    r.m[0] = (1 - 2 * (y * y + z * z)) * sc[0]; r.m[1] = (2 * (x * y + z * w)) * sc[0]; r.m[2] = (2 * (x * z - y * w)) * sc[0];
+    r.m[4] = (2 * (x * y - z * w)) * sc[1]; r.m[5] = (1 - 2 * (x * x + z * z)) * sc[1]; r.m[6] = (2 * (y * z + x * w)) * sc[1];
+    r.m[8] = (2 * (x * z + y * w)) * sc[2]; r.m[9] = (2 * (y * z - x * w)) * sc[2]; r.m[10] = (1 - 2 * (x * x + y * y)) * sc[2];
+    r.m[12] = t[0]; r.m[13] = t[1]; r.m[14] = t[2];
+    return r;
+}
+// inverse transpose of the upper 3x3 (cofactor matrix / det): how normals transform
+void normal_matrix(const Mat4 &w, double n[9]) {
+    const double a = w.m[0], b = w.m[4], c = w.m[8], d = w.m[1], e = w.m[5], f = w.m[9], g = w.m[2], h = w.m[6], i = w.m[10];
+    const double co[9] = { e * i - f * h, f * g - d * i, d * h - e * g, c * h - b * i, a * i - c * g, b * g - a * h, b * f - c * e, c * d - a * f, a * e - b * d };
+    const double det = a * co[0] + b * co[1] + c * co[2];
+    const double s = det != 0 ? 1.0 / det : 1.0;
+    for (int k = 0; k < 9; k++) n[k] = co[k] * s;       // n[3*row + col] = cofactor(row, col) / det  == (M^-1)^T
+}
+
+}  // namespace
+
+static void load_strict_geometry(const JsonValue &root, const std::vector<std::pair<const uint8_t *, size_t>> &buffers,
+                                 const std::vector<BufferView> &views, HostScene &out) {
+    const JsonValue &jnodes = root.at("nodes");
+    const JsonValue &jmeshes = root.at("meshes");
+    int32_t default_material = -1;
+    // roots: the default scene's (or scene 0's) nodes; without scenes, every node that is nobody's child
+    std::vector<size_t> roots;
+    const JsonValue &jscenes = root.at("scenes");
+    if (jscenes.size() > 0) {
+        size_t which = (size_t)std::max<long long>(0, root.at("scene").as_int(0));
+        if (which >= jscenes.size()) which = 0;
+        const JsonValue &list = jscenes.at(which).at("nodes");
+        for (size_t i = 0; i < list.size(); i++) roots.push_back((size_t)list.at(i).as_int(0));
+    } else {
+        std::vector<char> is_child(jnodes.size(), 0);
+        for (size_t n = 0; n < jnodes.size(); n++) {
+            const JsonValue &ch = jnodes.at(n).at("children");
+            for (size_t i = 0; i < ch.size(); i++) { const long long c = ch.at(i).as_int(-1); if (c >= 0 && (size_t)c < jnodes.size()) is_child[(size_t)c] = 1; }
+        }
+        for (size_t n = 0; n < jnodes.size(); n++) if (!is_child[n]) roots.push_back(n);
+    }
+    struct Item { size_t node; Mat4 world; int depth; };
+    std::vector<Item> stack;
+    for (size_t i = roots.size(); i-- > 0;) stack.push_back(Item{ roots[i], identity(), 0 });
+    while (!stack.empty()) {
+        const Item it = stack.back();
+        stack.pop_back();
+        if (it.node >= jnodes.size()) throw std::runtime_error("node index out of range");
+        if (it.depth > 256) throw std::runtime_error("node hierarchy deeper than 256 levels (a cycle?)");
+        const JsonValue &node = jnodes.at(it.node);
+        const Mat4 world = mul(it.world, local_matrix(node));
+        const JsonValue &ch = node.at("children");
+        for (size_t i = ch.size(); i-- > 0;) stack.push_back(Item{ (size_t)ch.at(i).as_int(0), world, it.depth + 1 });
+        const long long mesh_index = node.at("mesh").as_int(-1);
+        if (mesh_index < 0) continue;                               // cameras, lights, empties
+        if ((size_t)mesh_index >= jmeshes.size()) throw std::runtime_error("mesh index out of range");
+        double nm[9];
+        normal_matrix(world, nm);
+        bool untransformed = true;                                  // identity: hand the file's floats through untouched
+        for (int k = 0; k < 16; k++) untransformed = untransformed && world.m[k] == (k % 5 == 0 ? 1.0 : 0.0);
+        std::vector<float> pos, nrm, uv;
+        std::vector<int32_t> mat;
+        const JsonValue &prims = jmeshes.at((size_t)mesh_index).at("primitives");
+        for (size_t p = 0; p < prims.size(); p++) {
+            const JsonValue &prim = prims.at(p);
+            const long long mode = prim.at("mode").as_int(4);
+            if (mode < 4) continue;                                 // points and lines are not renderable here
+            if (mode != 4) throw UnsupportedError("triangle strips / fans");
+            const JsonValue &attrs = prim.at("attributes");
+            if (!attrs.has("POSITION")) continue;
+            const Accessor ap = open_accessor(root, buffers, views, attrs.at("POSITION").as_int(-1), 3);
+            const bool has_n = attrs.has("NORMAL"), has_t = attrs.has("TEXCOORD_0");
+            Accessor an, at_;
+            if (has_n) an = open_accessor(root, buffers, views, attrs.at("NORMAL").as_int(-1), 3);
+            if (has_t) at_ = open_accessor(root, buffers, views, attrs.at("TEXCOORD_0").as_int(-1), 2);
+            Accessor ai;
+            const bool indexed = prim.has("indices");
+            if (indexed) ai = open_accessor(root, buffers, views, prim.at("indices").as_int(-1), 1);
+            const size_t n_idx = indexed ? ai.count : ap.count;
+            int32_t material = (int32_t)prim.at("material").as_int(-1);
+            if (material < 0) {                                     // the specification's default material: white, untextured
+                if (default_material < 0) {
+                    drt_material m;
+                    std::memset(&m, 0, sizeof m);
+                    m.albedo[0] = m.albedo[1] = m.albedo[2] = 1; m.albedo_tex = -1; m.roughness = 1; m.metallic = 1; m.refractive_index = 1.45f;
+                    default_material = (int32_t)out.materials.size();
+                    out.materials.push_back(m);
+                }
+                material = default_material;
+            }
+            for (size_t t = 0; t + 3 <= n_idx; t += 3) {
+                double wp[3][3];
+                for (int k = 0; k < 3; k++) {
+                    const size_t v = indexed ? (size_t)ai.get(t + (size_t)k, 0) : t + (size_t)k;
+                    if (v >= ap.count || (has_n && v >= an.count) || (has_t && v >= at_.count)) throw std::runtime_error("vertex index out of range");
+                    const double x = ap.get(v, 0), y = ap.get(v, 1), z = ap.get(v, 2);
+                    if (untransformed) { wp[k][0] = x; wp[k][1] = y; wp[k][2] = z; }
+                    else for (int r = 0; r < 3; r++) wp[k][r] = world.m[r] * x + world.m[4 + r] * y + world.m[8 + r] * z + world.m[12 + r];
+                    for (int r = 0; r < 3; r++) pos.push_back((float)wp[k][r]);
+                    if (has_t) { uv.push_back((float)at_.get(v, 0)); uv.push_back((float)at_.get(v, 1)); }
+                    else { uv.push_back(0.f); uv.push_back(0.f); }
+                    if (has_n) {
+                        const double nx = an.get(v, 0), ny = an.get(v, 1), nz = an.get(v, 2);
+                        if (untransformed) { nrm.push_back((float)nx); nrm.push_back((float)ny); nrm.push_back((float)nz); continue; }
+                        double w3[3];
+                        for (int r = 0; r < 3; r++) w3[r] = nm[3 * r] * nx + nm[3 * r + 1] * ny + nm[3 * r + 2] * nz;
+                        const double len = std::sqrt(w3[0] * w3[0] + w3[1] * w3[1] + w3[2] * w3[2]);
+                        for (int r = 0; r < 3; r++) nrm.push_back((float)(len > 0 ? w3[r] / len : w3[r]));
+                    }
+                }
+                if (!has_n) {                                       // flat shading: the geometric normal (counter-clockwise front)
+                    const double e1[3] = { wp[1][0] - wp[0][0], wp[1][1] - wp[0][1], wp[1][2] - wp[0][2] };
+                    const double e2[3] = { wp[2][0] - wp[0][0], wp[2][1] - wp[0][1], wp[2][2] - wp[0][2] };
+                    double g[3] = { e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0] };
+                    const double len = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+                    for (int k = 0; k < 3; k++) for (int r = 0; r < 3; r++) nrm.push_back((float)(len > 0 ? g[r] / len : 0.0));
+                }
+                mat.push_back(material);
+            }
+        }
+        for (int32_t m : mat)
+            if (m < 0 || (size_t)m >= out.materials.size()) throw std::runtime_error("primitive.material out of range");
+        if (!mat.empty()) out.set_geometry(pos.data(), nrm.data(), uv.data(), mat.data(), (int32_t)mat.size());
+    }
+}
+
+void HostScene::load_gltf(const char *path, bool strict) {
     std::string spath(path ? path : "");
     size_t dot_at = spath.find_last_of('.');
     std::string ext = dot_at == std::string::npos ? "" : spath.substr(dot_at + 1);
@@ -175,6 +377,7 @@ void HostScene::load_gltf(const char *path) {
         v.buffer = jviews.at(i).at("buffer").as_int(0);
         v.offset = jviews.at(i).at("byteOffset").as_int(0);
         v.length = jviews.at(i).at("byteLength").as_int(0);
+        v.stride = jviews.at(i).at("byteStride").as_int(0);
         if (v.buffer < 0 || (size_t)v.buffer >= buffers.size() || v.offset < 0 || v.length < 0 ||
             (size_t)(v.offset + v.length) > buffers[(size_t)v.buffer].second)
             throw std::runtime_error("bufferView out of range");
@@ -233,7 +436,12 @@ void HostScene::load_gltf(const char *path) {
         for (int k = 0; k < 3; k++) m.albedo[k] = (float)(col.size() >= 3 ? col.at((size_t)k).as_double(1.0) : 1.0);
         const JsonValue &em = jmats.at(i).at("emissiveFactor");
         for (int k = 0; k < 3; k++) m.emissive[k] = (float)(em.size() >= 3 ? em.at((size_t)k).as_double(0.0) : 0.0);
-        m.albedo_tex = (int32_t)pbr.at("baseColorTexture").at("index").as_int(-1);
+        m.albedo_tex = (int32_t)pbr.at("baseColorTexture").at("index").as_int(-1);     // used as IMAGE index (Scene.cu:79)
+        if (strict && m.albedo_tex >= 0) {                                             // spec: textures[index].source
+            const JsonValue &jtex = root.at("textures");
+            if ((size_t)m.albedo_tex >= jtex.size()) throw std::runtime_error("baseColorTexture.index out of range");
+            m.albedo_tex = (int32_t)jtex.at((size_t)m.albedo_tex).at("source").as_int(-1);
+        }
         m.roughness = (float)pbr.at("roughnessFactor").as_double(1.0);
         m.metallic = pbr.at("metallicFactor").as_double(1.0) > 0;
         m.transmission = 0;
@@ -241,10 +449,11 @@ void HostScene::load_gltf(const char *path) {
         fresh.materials.push_back(m);
     }
 
-    // loadGLTFmodel (Scene.cu:192-314): every NODE contributes its mesh; transforms are ignored
     const JsonValue &jnodes = root.at("nodes");
     const JsonValue &jmeshes = root.at("meshes");
-    for (size_t n = 0; n < jnodes.size(); n++) {
+    if (strict) load_strict_geometry(root, buffers, views, fresh);
+    // loadGLTFmodel (Scene.cu:192-314): every NODE contributes its mesh; transforms are ignored
+    for (size_t n = 0; !strict && n < jnodes.size(); n++) {
         int64_t mesh_index = jnodes.at(n).at("mesh").as_int(-1);
         if (mesh_index < 0 || (size_t)mesh_index >= jmeshes.size())
             throw UnsupportedError("node without a mesh: the reference indexes meshes[-1] here (Scene.cu:199-200)");

@@ -40,7 +40,8 @@ public:
     static uint64_t next_revision();
 
     void clear();
-    void load_gltf(const char *path);        // throws std::runtime_error / UnsupportedError
+    // strict = false: the reference's reading of the file, quirks included (Scene.cu); true: the glTF 2.0 specification's
+    void load_gltf(const char *path, bool strict = false);        // throws std::runtime_error / UnsupportedError
     void set_geometry(const float *pos, const float *nrm, const float *uv, const int32_t *mat, int32_t n_tris);
     void build_bvh(int32_t target_leaf_prims, int32_t bin_count);   // throws BvhError when the reference would hang
     int32_t bvh_depth() const;

@@ -109,7 +109,11 @@ struct Scene {
     Scene(const Scene &) = delete;
     Scene &operator=(const Scene &) = delete;
 
-    bool loadGLTFmodel(const char *filepath) { drt::check(drt_scene_load_gltf(handle, filepath)); return true; }
+    // strict = true: read the file as the glTF 2.0 specification defines it (drt.h DRT_LOAD_STRICT) instead of as Scene.cu does
+    bool loadGLTFmodel(const char *filepath, bool strict = false) {
+        drt::check(drt_scene_load_gltf_ex(handle, filepath, strict ? DRT_LOAD_STRICT : 0u));
+        return true;
+    }
 
     // what the editor's metrics panel reads from m_Meshes / m_Material / m_Textures (EditorLayer.cpp:57-65)
     size_t meshCount() const { return (size_t)drt_scene_mesh_count(handle); }

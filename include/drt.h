@@ -129,6 +129,12 @@ void        drt_camera_move(float position[3], const float right[3], const float
 drt_scene *drt_scene_create(void);
 void       drt_scene_destroy(drt_scene *s);                                   /* Scene::~Scene, Scene.cu:319-344 */
 int        drt_scene_load_gltf(drt_scene *s, const char *path);               /* Scene::loadGLTFmodel */
+/* flags = 0: as above.  DRT_LOAD_STRICT: read the file as the glTF 2.0 specification defines it instead of as the
+ * reference's loader does (Scene.cu:120-200 ignores node transforms and the scene graph, accessor byteOffset /
+ * componentType / byteStride, reads indices as u16 from byte 0 of the buffer, uses texture indices as image indices, and
+ * crashes on nodes without a mesh).  A file that satisfies the reference's assumptions loads identically either way. */
+#define DRT_LOAD_STRICT 1u
+int        drt_scene_load_gltf_ex(drt_scene *s, const char *path, uint32_t flags);
 /* Programmatic alternative to a file: de-indexed streams, 3 vertices per triangle. */
 int        drt_scene_set_geometry(drt_scene *s, const float *positions, const float *normals, const float *uvs,
                                   const int32_t *material_ids, int32_t n_tris);

@@ -279,3 +279,146 @@ def test_ascii_gltf_with_data_uris_and_external_files(tmp_path):
     with pytest.raises(drt.DrtError) as e:                      # the image file is gone
         drt.Scene().loadGLTFmodel(str(tmp_path / "a.gltf"))
     assert e.value.code == drt.ERR_IO
+
+
+def _tri_bytes(sc):
+    return np.ascontiguousarray(sc.m_PrimitivesBuffer).view(np.uint8)
+
+
+@pytest.mark.parametrize("name", ["bvh_split_test", "cornell_box", "cornell_box_gltf", "cs16_dust", "dense_monkey", "mc_transparency",
+                                  "multi_material", "sunshadow_test", "suzanne_plane", "uv_texture_gltf", "uv_texture_test"])
+def test_strict_loading_equals_reference_loading_where_the_assumptions_hold(name):
+    """DRT_LOAD_STRICT reads the file as the glTF specification says; the default reads it as Scene.cu does.  For files
+    that meet the reference's assumptions (u16 indices at the start of their buffer view, tightly packed attributes, no
+    transforms, texture i = image i, flat node list) the two must give the same 128-byte triangle records, bit for bit."""
+    a, b = drt.Scene(), drt.Scene()
+    a.loadGLTFmodel(scene_path(name))
+    b.loadGLTFmodel(scene_path(name), strict=True)
+    assert np.array_equal(_tri_bytes(a), _tri_bytes(b))
+    assert np.array_equal(a.m_Material["albedo_tex"], b.m_Material["albedo_tex"])
+
+
+def test_strict_loading_honours_what_the_reference_ignores(tmp_path):
+    """A GLB built to break every assumption of Scene.cu:120-200: u32 indices behind an accessor byteOffset, interleaved
+    vertices (byteStride), a parent node with translation + rotation + scale, a child with a matrix, an empty node, the
+    same mesh used by two nodes, a primitive without NORMAL / TEXCOORD_0 / material / indices, texture -> image
+    indirection.  Expected geometry is computed here with numpy in float64."""
+    import json
+    import struct
+    rng = np.random.default_rng(11)
+    # mesh 0: a quad, interleaved (pos3, nrm3, uv2 = 32 bytes) with 8 bytes of padding per vertex (stride 40), u32 indices
+    quad_p = np.float32([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]])
+    quad_n = np.float32([[0, 0, 1]] * 4)
+    quad_t = np.float32([[0, 0], [1, 0], [1, 1], [0, 1]])
+    inter = np.zeros((4, 10), np.float32)
+    inter[:, 0:3], inter[:, 3:6], inter[:, 6:8] = quad_p, quad_n, quad_t
+    idx32 = np.uint32([0, 1, 2, 0, 2, 3])
+    # mesh 1: one non-indexed triangle with positions only
+    tri_p = np.float32([[0, 0, 0], [2, 0, 0], [0, 2, 0]])
+    chunks, views = [], []
+
+    def add_view(data, stride=None):
+        off = sum(len(c) for c in chunks)
+        pad = (-off) % 4
+        if pad:
+            chunks.append(b"\0" * pad)
+            off += pad
+        chunks.append(bytes(data))
+        v = {"buffer": 0, "byteOffset": off, "byteLength": len(data)}
+        if stride:
+            v["byteStride"] = stride
+        views.append(v)
+        return len(views) - 1
+    v_inter = add_view(inter.tobytes(), 40)
+    v_idx = add_view(b"\xAA" * 12 + idx32.tobytes())            # 12 junk bytes, then the indices (accessor byteOffset 12)
+    v_tri = add_view(tri_p.tobytes())
+    png = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "png", "rgb8.png"), "rb").read()
+    png2 = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "png", "rgba8.png"), "rb").read()
+    v_png, v_png2 = add_view(png), add_view(png2)
+    q = np.array([0.0, 0.0, np.sin(np.pi / 8), np.cos(np.pi / 8)])          # 45 degrees about z
+    child_matrix = np.eye(4)
+    child_matrix[:3, 3] = [0, 0, 5]
+    child_matrix[0, 0] = 2
+    gltf = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0, 3]}],
+            "nodes": [{"children": [1, 2], "translation": [1, 2, 3], "rotation": q.tolist(), "scale": [2, 2, 2]},
+                      {"mesh": 0, "matrix": child_matrix.T.reshape(-1).tolist()},
+                      {"name": "empty"},
+                      {"mesh": 0}, ],
+            "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2}, "indices": 3, "material": 0},
+                                       {"attributes": {"POSITION": 4}}]}],
+            "accessors": [{"bufferView": v_inter, "byteOffset": 0, "componentType": 5126, "count": 4, "type": "VEC3"},
+                          {"bufferView": v_inter, "byteOffset": 12, "componentType": 5126, "count": 4, "type": "VEC3"},
+                          {"bufferView": v_inter, "byteOffset": 24, "componentType": 5126, "count": 4, "type": "VEC2"},
+                          {"bufferView": v_idx, "byteOffset": 12, "componentType": 5125, "count": 6, "type": "SCALAR"},
+                          {"bufferView": v_tri, "componentType": 5126, "count": 3, "type": "VEC3"}],
+            "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [0.5, 0.6, 0.7, 1], "baseColorTexture": {"index": 0}}}],
+            "textures": [{"source": 1}], "images": [{"bufferView": v_png, "mimeType": "image/png"}, {"bufferView": v_png2, "mimeType": "image/png"}],
+            "bufferViews": views, "buffers": [{"byteLength": 0}]}
+    binary = b"".join(chunks)
+    binary += b"\0" * ((-len(binary)) % 4)
+    gltf["buffers"][0]["byteLength"] = len(binary)
+    js = json.dumps(gltf).encode()
+    js += b" " * ((-len(js)) % 4)
+    glb = b"glTF" + struct.pack("<II", 2, 12 + 8 + len(js) + 8 + len(binary)) + struct.pack("<I", len(js)) + b"JSON" + js + struct.pack("<I", len(binary)) + b"BIN\0" + binary
+    path = tmp_path / "strict.glb"
+    path.write_bytes(glb)
+
+    sc = drt.Scene()
+    sc.loadGLTFmodel(str(path), strict=True)
+    tris = sc.m_PrimitivesBuffer
+    # expected: DFS from the scene's roots: node0 (no mesh) -> child 1 (mesh 0) -> child 2 (empty) ; then node 3 (mesh 0)
+    x, y, z, w = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    M0 = np.eye(4)
+    M0[:3, :3] = R * 2.0
+    M0[:3, 3] = [1, 2, 3]
+    W1 = M0 @ child_matrix
+
+    def instance(Wm):
+        out = []
+        for tri in (idx32[:3], idx32[3:]):
+            out.append(((Wm[:3, :3] @ quad_p[tri].astype(np.float64).T).T + Wm[:3, 3], 0))
+        out.append(((Wm[:3, :3] @ tri_p.astype(np.float64).T).T + Wm[:3, 3], 1))
+        return out
+    want = instance(W1) + instance(np.eye(4))
+    assert len(tris) == len(want) == 6
+    for t, (p, m) in zip(tris, want):
+        assert np.allclose(t["vertex"]["position"], p, rtol=1e-6, atol=1e-6)
+        assert int(t["material"]) == m
+    mats = sc.m_Material
+    assert len(mats) == 2 and int(mats["albedo_tex"][0]) == 1 and int(mats["albedo_tex"][1]) == -1      # textures[0].source = image 1; default material
+    assert np.allclose(mats["albedo"][1], 1.0)
+    # the untransformed instance keeps the file's floats; the transformed quad's normals follow the rotation (z stays z here)
+    assert np.array_equal(tris[3]["vertex"]["position"], quad_p[idx32[:3]]) and np.array_equal(tris[3]["vertex"]["normal"], quad_n[:3])
+    assert np.allclose(tris[0]["vertex"]["normal"], [[0, 0, 1]] * 3, atol=1e-6) and np.array_equal(tris[0]["vertex"]["uv"], quad_t[idx32[:3]])
+    # no NORMAL: geometric normal; no TEXCOORD_0: zeros
+    assert np.allclose(np.abs(tris[5]["face_normal"]), [0, 0, 1]) and not tris[5]["vertex"]["uv"].any()
+    assert [(int(m["primitives_offset"]), int(m["tris_count"])) for m in sc.m_Meshes] == [(0, 3), (3, 3)]
+    # the reference's reading of the same file: node 0 has no mesh -> the error that stands for its crash
+    with pytest.raises(drt.DrtError):
+        drt.Scene().loadGLTFmodel(str(path))
+    b = drt.BVHBuilder()
+    b.buildIterative(sc)
+    assert len(sc.m_BVHNodes) == 1
+
+
+def test_strict_loading_of_the_reference_scenes_with_transforms():
+    """suzanne_plane.gltf carries node translations the reference drops; room.glb's second mesh has no TEXCOORD_0 (the
+    reference reads unrelated bytes as UVs); lightweightRTtest.glb nests nodes (the reference walks the flat node list)."""
+    a, b = drt.Scene(), drt.Scene()
+    a.loadGLTFmodel(scene_path("suzanne_plane_gltf"))
+    b.loadGLTFmodel(scene_path("suzanne_plane_gltf"), strict=True)
+    pa, pb = a.m_PrimitivesBuffer["vertex"]["position"], b.m_PrimitivesBuffer["vertex"]["position"]
+    assert pa.shape == pb.shape and not np.allclose(pa, pb)
+    a.loadGLTFmodel(scene_path("room"))
+    b.loadGLTFmodel(scene_path("room"), strict=True)
+    ta, tb = a.m_PrimitivesBuffer, b.m_PrimitivesBuffer
+    assert np.array_equal(ta["vertex"]["position"], tb["vertex"]["position"])
+    assert not np.array_equal(ta["vertex"]["uv"], tb["vertex"]["uv"])
+    a.loadGLTFmodel(scene_path("lightweight_rt"))
+    b.loadGLTFmodel(scene_path("lightweight_rt"), strict=True)
+    ca = np.sort(a.m_PrimitivesBuffer["centroid"].view([("x", "<f4"), ("y", "<f4"), ("z", "<f4")]).reshape(-1), order=["x", "y", "z"])
+    cb = np.sort(b.m_PrimitivesBuffer["centroid"].view([("x", "<f4"), ("y", "<f4"), ("z", "<f4")]).reshape(-1), order=["x", "y", "z"])
+    assert len(ca) == len(cb) == 542
