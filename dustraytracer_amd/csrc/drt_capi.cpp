@@ -98,7 +98,8 @@ struct drt_renderer {
     int num_cus = 256;
     bool use_pixel_walk = false;              // DRT_KERNEL=pixel_walk selects the first (non-persistent) kernel
     bool scene_has_alpha = false;
-    int vote_node = 12, vote_shade = 36, vote_dir = 4, vote_spec = 8;   // wave_queue phase-voting thresholds (DRT_VOTE_N/S/R/P override)
+    int vote_node = 12, vote_shade = 36, vote_dir = 4, vote_spec = 8;
+    int vote_tail_node = 4, vote_tail_shade = 36;    // once the queue is empty (DRT_VOTE_TN / DRT_VOTE_TS): pops stop waiting for company   // wave_queue phase-voting thresholds (DRT_VOTE_N/S/R/P override)
     const char *kernel_name = "";
     int launch_shape[3] = { 0, 0, 0 };       // wave_queue: stack slots per lane, workgroups per CU, LDS KiB per workgroup
     // device copy of the scene last rendered
@@ -293,6 +294,8 @@ drt_renderer *drt_renderer_create(int32_t device) {
     r->vote_shade = std::max(1, env_int("DRT_VOTE_S", r->vote_shade));
     r->vote_dir = std::max(1, env_int("DRT_VOTE_R", r->vote_dir));
     r->vote_spec = std::max(1, env_int("DRT_VOTE_P", r->vote_spec));
+    r->vote_tail_node = std::max(1, env_int("DRT_VOTE_TN", r->vote_tail_node));
+    r->vote_tail_shade = std::max(1, env_int("DRT_VOTE_TS", r->vote_tail_shade));
     r->sample_budget = (size_t)std::max(1, env_int("DRT_SAMPLE_MB", 1024)) << 20;
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) r->num_cus = cus;
@@ -512,7 +515,7 @@ static void fill_frame_params(const drt_renderer *r, const drt_camera *cam, Fram
     fp.stripe_rows = r->stripe_rows; fp.rank = r->rank; fp.world = r->world; fp.local_rows = r->local_rows;
     fp.accum = r->cur_accum(); fp.rgba = r->cur_rgba();
     fp.counters = r->counting ? r->counters : nullptr;
-    fp.vote_node = r->vote_node; fp.vote_shade = r->vote_shade; fp.vote_dir = r->vote_dir; fp.vote_spec = r->vote_spec;
+    fp.vote_node = r->vote_node; fp.vote_shade = r->vote_shade; fp.vote_dir = r->vote_dir; fp.vote_spec = r->vote_spec; fp.vote_tail_node = r->vote_tail_node; fp.vote_tail_shade = r->vote_tail_shade;
 }
 
 static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_scene *scene, uint32_t n_frames,

@@ -170,7 +170,8 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
         return sc.leaves[id];
     };
 
-    const int vote_node = fp.vote_node, vote_shade = fp.vote_shade, vote_dir = fp.vote_dir;
+    int vote_node = fp.vote_node, vote_shade = fp.vote_shade;
+    const int vote_dir = fp.vote_dir;
     const bool debug = GENERAL && fp.render_mode == 1;
     const bool sun = SUN || (GENERAL && fp.enable_sunlight && !debug);
     const f3 root_min = ld3(sc.root_min), root_max = ld3(sc.root_max);
@@ -347,6 +348,10 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
                         if (!exhausted && lane == 0) c = atomicAdd(chunk_counter, 1u);
                         c = __builtin_amdgcn_readfirstlane(c);
                         if (exhausted || c >= n_chunks) {
+                            // the queue is empty: no new paths will refill this wave's lanes.  From here on what matters is
+                            // how long the wave's slowest path takes, not how full its phases run, so lanes stop waiting for
+                            // company before they shade or pop
+                            if (!exhausted) { vote_shade = min(vote_shade, fp.vote_tail_shade); vote_node = min(vote_node, fp.vote_tail_node); }
                             exhausted = true;
                             if (need) { stage = kFinished; need = false; }
                             break;
