@@ -192,7 +192,7 @@ DRT_DEV bool tri_intersect(const Ray &ray, f3 v0, f3 e1, f3 e2, float &t_out, f3
 DRT_DEV bool tri_intersect_flat(const Ray &ray, f3 v0, f3 e1, f3 e2, float &t, float &u, float &v) {
     f3 pvec = cross(ray.dir, e2);
     float det = dot(e1, pvec);
-    bool ok = !((det > -DRT_TRIANGLE_EPSILON) & (det < DRT_TRIANGLE_EPSILON));
+    int ok = !((int)(det > -DRT_TRIANGLE_EPSILON) & (int)(det < DRT_TRIANGLE_EPSILON));     // ints: no short-circuit branches
     float inv_det = exact_rcp_not_tiny(det);          // !ok covers |det| < 1e-6: whatever comes back there is not used
     f3 tvec = ray.orig - v0;
     u = inv_det * dot(tvec, pvec);
@@ -200,10 +200,10 @@ DRT_DEV bool tri_intersect_flat(const Ray &ray, f3 v0, f3 e1, f3 e2, float &t, f
     v = inv_det * dot(ray.dir, qvec);
     // (u < 0 | v < 0) and (u > 1 | u + v > 1) through v_min / v_max, which drop a NaN operand exactly as the two separate
     // comparisons ignore it (a compare + mask costs ~4 cycles on gfx950, min/max 2)
-    ok = ok & (bool)(!(fminf(u, v) < 0.0f)) & (bool)(!(fmaxf(u, u + v) > 1.0f));
+    ok = ok & (int)(!(fminf(u, v) < 0.0f)) & (int)(!(fmaxf(u, u + v) > 1.0f));
     t = inv_det * dot(e2, qvec);
-    ok = ok & (t > DRT_TRIANGLE_EPSILON);
-    return ok;
+    ok = ok & (int)(t > DRT_TRIANGLE_EPSILON);
+    return ok != 0;
 }
 
 // ---- Shaders/RayGen.cuh:23-61 ----

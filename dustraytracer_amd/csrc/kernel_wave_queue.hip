@@ -70,10 +70,10 @@ DRT_DEV uint2 lds_load2(uint32_t byte_off) {
     return make_uint2(v.x, v.y);
 }
 DRT_DEV uint32_t lds_load1(uint32_t byte_off) { return *(__attribute__((address_space(3))) const uint32_t *)byte_off; }
-#else       // host pass: declarations only (never called on the host)
-uint4 lds_load4(uint32_t byte_off);
-uint2 lds_load2(uint32_t byte_off);
-uint32_t lds_load1(uint32_t byte_off);
+#else       // host pass: never called, only parsed
+inline uint4 lds_load4(uint32_t) { return make_uint4(0, 0, 0, 0); }
+inline uint2 lds_load2(uint32_t) { return make_uint2(0, 0); }
+inline uint32_t lds_load1(uint32_t) { return 0; }
 #endif
 DRT_DEV int lane_rank(unsigned long long mask) {        // set bits below this lane
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
