@@ -102,57 +102,60 @@ struct BitReader {
 
 inline uint8_t clamp255(int x) { return (unsigned)x > 255 ? (x < 0 ? 0 : 255) : (uint8_t)x; }
 
-// One 1-D pass of the LLM inverse DCT on eight values; constants are round(c * 4096).
-#define DRT_F2F(x) ((int)((x) * 4096 + 0.5))
-#define DRT_IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                   \
-    int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                           \
-    p2 = s2; p3 = s6;                                                                  \
-    p1 = (p2 + p3) * DRT_F2F(0.5411961f);                                              \
-    t2 = p1 + p3 * DRT_F2F(-1.847759065f);                                             \
-    t3 = p1 + p2 * DRT_F2F(0.765366865f);                                              \
-    p2 = s0; p3 = s4;                                                                  \
-    t0 = (p2 + p3) * 4096;                                                             \
-    t1 = (p2 - p3) * 4096;                                                             \
-    x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;                           \
-    t0 = s7; t1 = s5; t2 = s3; t3 = s1;                                                \
-    p3 = t0 + t2; p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;                           \
-    p5 = (p3 + p4) * DRT_F2F(1.175875602f);                                            \
-    t0 = t0 * DRT_F2F(0.298631336f);                                                   \
-    t1 = t1 * DRT_F2F(2.053119869f);                                                   \
-    t2 = t2 * DRT_F2F(3.072711026f);                                                   \
-    t3 = t3 * DRT_F2F(1.501321110f);                                                   \
-    p1 = p5 + p1 * DRT_F2F(-0.899976223f);                                             \
-    p2 = p5 + p2 * DRT_F2F(-2.562915447f);                                             \
-    p3 = p3 * DRT_F2F(-1.961570560f);                                                  \
-    p4 = p4 * DRT_F2F(-0.390180644f);                                                  \
-    t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
+// One 1-D pass of the LLM inverse DCT (Loeffler, Ligtenberg, Moschytz 1989; the IJG library's "islow" factorisation) on
+// eight values, constants in 12-bit fixed point.  The eight outputs are even[k] + odd[k] (k = 0..3) and, mirrored,
+// even[k] - odd[k]; the caller adds its rounding bias to the even part and shifts.
+constexpr int fix12(double c) { return (int)(c * 4096 + 0.5); }       // C truncation, also for the negative constants
+struct Butterfly { int even[4], odd[4]; };
+inline Butterfly idct8(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7) {
+    Butterfly r;
+    // even part: one rotation for (s2, s6), one butterfly for (s0, s4)
+    const int rot = (s2 + s6) * fix12(0.5411961f);
+    const int lo = rot + s6 * fix12(-1.847759065f);
+    const int hi = rot + s2 * fix12(0.765366865f);
+    const int sum = (s0 + s4) * 4096, diff = (s0 - s4) * 4096;
+    r.even[0] = sum + hi; r.even[3] = sum - hi;
+    r.even[1] = diff + lo; r.even[2] = diff - lo;
+    // odd part: (s7, s5, s3, s1) through the shared term of the four rotations
+    const int a = s7 + s3, b = s5 + s1, c = s7 + s1, d = s5 + s3;
+    const int shared = (a + b) * fix12(1.175875602f);
+    const int c_term = shared + c * fix12(-0.899976223f);
+    const int d_term = shared + d * fix12(-2.562915447f);
+    const int a_term = a * fix12(-1.961570560f);
+    const int b_term = b * fix12(-0.390180644f);
+    r.odd[3] = s7 * fix12(0.298631336f) + c_term + a_term;       // pairs with even[3]
+    r.odd[2] = s5 * fix12(2.053119869f) + d_term + b_term;
+    r.odd[1] = s3 * fix12(3.072711026f) + d_term + a_term;
+    r.odd[0] = s1 * fix12(1.501321110f) + c_term + b_term;
+    return r;
+}
 
-void idct_block(uint8_t *out, int stride, const short data[64]) {
-    int val[64];
-    for (int i = 0; i < 8; i++) {                    // columns
-        const short *d = data + i;
-        int *v = val + i;
-        if (d[8] == 0 && d[16] == 0 && d[24] == 0 && d[32] == 0 && d[40] == 0 && d[48] == 0 && d[56] == 0) {
-            const int dc = d[0] * 4;
-            v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dc;
-        } else {
-            DRT_IDCT_1D(d[0], d[8], d[16], d[24], d[32], d[40], d[48], d[56])
-            x0 += 512; x1 += 512; x2 += 512; x3 += 512;
-            v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10;
-            v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
-            v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10;
-            v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
+void idct_block(uint8_t *out, int stride, const short coef[64]) {
+    int mid[64];
+    for (int col = 0; col < 8; col++) {              // columns -> 10 fractional bits dropped
+        const short *c = coef + col;
+        int *m = mid + col;
+        if (!(c[8] | c[16] | c[24] | c[32] | c[40] | c[48] | c[56])) {      // DC-only column: every row gets 4 * DC
+            const int flat = c[0] * 4;
+            for (int row = 0; row < 8; row++) m[8 * row] = flat;
+            continue;
+        }
+        const Butterfly b = idct8(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56]);
+        for (int k = 0; k < 4; k++) {
+            const int e = b.even[k] + 512;
+            m[8 * k] = (e + b.odd[k]) >> 10;
+            m[8 * (7 - k)] = (e - b.odd[k]) >> 10;
         }
     }
-    for (int i = 0; i < 8; i++) {                    // rows (+128 level shift and rounding folded into the bias)
-        const int *v = val + 8 * i;
-        uint8_t *o = out + (size_t)i * stride;
-        DRT_IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
-        x0 += 65536 + (128 << 17); x1 += 65536 + (128 << 17); x2 += 65536 + (128 << 17); x3 += 65536 + (128 << 17);
-        o[0] = clamp255((x0 + t3) >> 17); o[7] = clamp255((x0 - t3) >> 17);
-        o[1] = clamp255((x1 + t2) >> 17); o[6] = clamp255((x1 - t2) >> 17);
-        o[2] = clamp255((x2 + t1) >> 17); o[5] = clamp255((x2 - t1) >> 17);
-        o[3] = clamp255((x3 + t0) >> 17); o[4] = clamp255((x3 - t0) >> 17);
+    for (int row = 0; row < 8; row++) {              // rows -> 17 bits dropped, +128 level shift and rounding in the bias
+        const int *m = mid + 8 * row;
+        uint8_t *o = out + (size_t)row * stride;
+        const Butterfly b = idct8(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
+        for (int k = 0; k < 4; k++) {
+            const int e = b.even[k] + 65536 + (128 << 17);
+            o[k] = clamp255((e + b.odd[k]) >> 17);
+            o[7 - k] = clamp255((e - b.odd[k]) >> 17);
+        }
     }
 }
 
