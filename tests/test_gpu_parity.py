@@ -509,3 +509,14 @@ def test_edge_case_scenes_and_frame_sizes(renderer):
     renderer.RenderBatch(cam, sc, 2)
     ref, _, _ = oracle.render(osc, ocam, o, 80, 45, 1, 2)
     compare(renderer.GetRenderTargetImage(), ref, "32 bounces")
+
+
+def test_randomised_cases_match_oracle():
+    """tools/fuzz_parity.py, a short run: random scene / camera / lens / settings / frame size, all kernel variants."""
+    import os
+    import subprocess
+    import sys
+    from tests.scenes import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "250", "31"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatching 0" in r.stdout
