@@ -184,14 +184,17 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
     bool shadow = false;             // current traversal is RayTest (BVHTraversal.cuh:76-134)
     bool occluded = false;
     Ray ray = make_ray(mk3(0, 0, 0), mk3(0, 0, 1));
-    float hit_t = FLT_MAX, hit_u = 0, hit_v = 0;
+    f3 hit_tuv = mk3(FLT_MAX, 0, 0);                                     // closest hit so far: distance and barycentrics
+    float &hit_t = hit_tuv.x, &hit_u = hit_tuv.y, &hit_v = hit_tuv.z;
     int hit_prim = -1;
     float heat = 0;
     f3 light = mk3(0, 0, 0), throughput = mk3(1, 1, 1);
     // Origin and normal of the next bounce, kept from the shaded hit until its direction is drawn.  Only a sun shadow
     // traversal still needs the ray in between, so the kernels without one keep them in the dead ray's registers.
     f3 bounce_origin_own = mk3(0, 0, 0), bounce_normal_own = mk3(0, 0, 0);
-    f3 &bounce_origin = SHADOWS ? bounce_origin_own : ray.orig;
+    // The lean sunlight kernels need the ray for the shadow traversal but no longer the hit record: the origin goes into
+    // the hit's three floats and the normal is re-derived from hit_prim (complemented when the face normal was flipped).
+    f3 &bounce_origin = SUN ? hit_tuv : (GENERAL ? bounce_origin_own : ray.orig);
     f3 &bounce_normal = SHADOWS ? bounce_normal_own : ray.dir;
     f2 tex_uv; tex_uv.x = 0; tex_uv.y = 1;
     uint32_t seed = 0, slot = 0;     // slot: where this sample's colour goes in `samples`
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
                 } else {
                     const f3 uvw = mk3(1.0f - hit_u - hit_v, hit_u, hit_v);                // Intersection.cu:31
                     f3 position, normal;                                                   // ClosestHit.cuh:13-24
-                    closest_hit_frame(ray, hit_t, fetch_face_normal(hit_prim), position, normal);
+                    const bool front_face = closest_hit_frame(ray, hit_t, fetch_face_normal(hit_prim), position, normal);
                     const TriCold cold = fetch_cold(hit_prim);                             // :111-118
                     const MatDev mat = fetch_mat(cold.material);
                     if (mat.tex < 0) {
@@ -277,7 +280,8 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
                         if (COUNT) c_htex++;
                     }
                     bounce_origin = position + (normal * 0.001f);                          // :121
-                    bounce_normal = normal;
+                    if (SUN) { if (!front_face) hit_prim = ~hit_prim; }                    // normal = +-face normal of hit_prim: re-derived at launch
+                    else bounce_normal = normal;
                     stage = kShadowDone;                                                   // (b) below, now or after the shadow ray
                     occluded = true;
                     if (sun) {                                                             // :124-128
@@ -321,6 +325,10 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
             // (b2) direction ready: launch the bounce ray  RayGen.cuh:133-134
             if (in_s && stage == kNeedDir && spec < 0) {
                 seed = spec_seed;
+                if (SUN) {
+                    const f3 fn = fetch_face_normal(hit_prim < 0 ? ~hit_prim : hit_prim);
+                    ray = make_ray(bounce_origin, (hit_prim < 0 ? (-1.f * fn) : fn) + spec_p);
+                } else
                 ray = make_ray(bounce_origin, bounce_normal + spec_p);
                 begin_closest();
                 stage = kTraceDone;
@@ -499,9 +507,10 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
                         const bool occ = (h0 && (!ALPHA || any_hit(sc, i, mk3(1.0f - u0 - v0, u0, v0)))) ||
                                          (h1 && (!ALPHA || any_hit(sc, j, mk3(1.0f - u1 - v1, u1, v1))));
                         if (occ) { occluded = true; cur = end = 0; sp = 0; }
-                    } else
-                    if (h0 && t0 < hit_t && (!ALPHA || any_hit(sc, i, mk3(1.0f - u0 - v0, u0, v0)))) { hit_t = t0; hit_prim = i; hit_u = u0; hit_v = v0; }
-                    if (h1 && t1 < hit_t && (!ALPHA || any_hit(sc, j, mk3(1.0f - u1 - v1, u1, v1)))) { hit_t = t1; hit_prim = j; hit_u = u1; hit_v = v1; }
+                    } else {
+                        if (h0 && t0 < hit_t && (!ALPHA || any_hit(sc, i, mk3(1.0f - u0 - v0, u0, v0)))) { hit_t = t0; hit_prim = i; hit_u = u0; hit_v = v0; }
+                        if (h1 && t1 < hit_t && (!ALPHA || any_hit(sc, j, mk3(1.0f - u1 - v1, u1, v1)))) { hit_t = t1; hit_prim = j; hit_u = u1; hit_v = v1; }
+                    }
                 }
             } else if (cur < end) {
                 const int i = cur++;
