@@ -11,6 +11,8 @@ CASES = [("cornell_box", 1920, 1080, 64, 8, {}), ("cs16_dust", 1920, 1080, 8, 5,
          ("suzanne_plane", 3840, 2160, 8, 4, {}), ("sunshadow_test", 1920, 1080, 8, 3, dict(enableSunlight=1)),
          ("room", 1920, 1080, 8, 16, {}), ("lightweight_rt", 1920, 1080, 16, 6, dict(enableSunlight=1)),
          ("dense_monkey", 1920, 1080, 8, 8, dict(tone_mapping=0))]
+if len(sys.argv) > 1 and sys.argv[1] == "c5":           # BASELINE config 5 whole: 531 M samples, several minutes of oracle time
+    CASES = [("room", 3840, 2160, 64, 16, {})]
 names = {"enableSunlight": "enable_sunlight"}
 r = drt.Renderer(0)
 bad_total = 0
