@@ -167,6 +167,7 @@ def main():
             self.r = drt.Renderer(local_rank)
             self.r.m_RendererSettings = drt.RendererSettings(ray_bounce_limit=depth, max_samples=spp + 1)
             self.r.setShard(STRIPE_ROWS, shard_rank, shard_world)
+            self.r.setFramesInFlight(max(1, args.frames_in_flight))
             self.r.ResizeBuffer(W, H)
             self.accum = torch.zeros((padded, W, 3), dtype=torch.float32, device=dev)
             self.rgba = torch.zeros((padded, W, 4), dtype=torch.float32, device=dev)

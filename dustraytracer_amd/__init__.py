@@ -217,6 +217,7 @@ _sig("drt_renderer_set_counting", C.c_int, _P, C.c_int32)
 _sig("drt_renderer_get_counters", C.c_int, _P, C.POINTER(Counters))
 _sig("drt_renderer_kernel_info", C.c_int, _P, C.c_char_p, C.c_size_t)
 _sig("drt_renderer_kernel_span", C.c_int, _P, C.POINTER(C.c_float))
+_sig("drt_renderer_set_frames_in_flight", C.c_int, _P, C.c_int32)
 _sig("drt_assemble_shards", C.c_int, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P)
 _sig("drt_shard_rows", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
 _sig("drt_debug_decode_image", C.c_int, _P, C.c_size_t, _P, _P, C.c_size_t)
@@ -426,6 +427,11 @@ class Renderer:
         c = Counters()
         _check(_lib.drt_renderer_get_counters(self._h, C.byref(c)))
         return c
+
+    def setFramesInFlight(self, n):
+        """Hint that n launches are kept in flight on this device (other renderers on other streams): small launches get
+        smaller grids so that they overlap.  Does not change results."""
+        _check(_lib.drt_renderer_set_frames_in_flight(self._h, int(n)))
 
     def kernelSpanMs(self):
         """Device-measured execution time of the tracing kernel(s) of the last completed batch (no queueing time)."""

@@ -100,6 +100,7 @@ struct FrameParams {
     unsigned long long *span;        // wave_queue: {max(~start), max(end)} of the kernel on the constant-rate wall clock, or nullptr
     // wave_queue phase voting: a phase other than T runs as soon as this many lanes wait for it
     int32_t vote_node, vote_shade, vote_dir, vote_spec;
+    int32_t frames_in_flight;         // launches the caller keeps in flight on this device (grid sizing of small launches)
     int32_t vote_tail_node, vote_tail_shade;   // thresholds once the sample queue is empty (drain of the launch)
 };
 

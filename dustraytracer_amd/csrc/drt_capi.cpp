@@ -96,6 +96,7 @@ struct drt_renderer {
     size_t samples_bytes = 0;
     size_t sample_budget = (size_t)1 << 30;   // frames of one batch are split so that a launch needs at most this much
     int num_cus = 256;
+    int frames_in_flight = 1;                 // drt_renderer_set_frames_in_flight
     bool use_pixel_walk = false;              // DRT_KERNEL=pixel_walk selects the first (non-persistent) kernel
     bool scene_has_alpha = false;
     int vote_node = 12, vote_shade = 36, vote_dir = 4, vote_spec = 8;
@@ -435,6 +436,12 @@ void drt_camera_move(float position[3], const float right[3], const float up[3],
     }
 }
 
+int drt_renderer_set_frames_in_flight(drt_renderer *r, int32_t n) {
+    if (!r || n < 1) return fail(DRT_ERR_INVALID, "bad argument");
+    r->frames_in_flight = n;
+    return DRT_OK;
+}
+
 int drt_renderer_kernel_span(const drt_renderer *r, float *ms) {
     if (!r || !ms) return fail(DRT_ERR_INVALID, "bad argument");
     *ms = r->span_ms;
@@ -515,7 +522,7 @@ static void fill_frame_params(const drt_renderer *r, const drt_camera *cam, Fram
     fp.stripe_rows = r->stripe_rows; fp.rank = r->rank; fp.world = r->world; fp.local_rows = r->local_rows;
     fp.accum = r->cur_accum(); fp.rgba = r->cur_rgba();
     fp.counters = r->counting ? r->counters : nullptr;
-    fp.vote_node = r->vote_node; fp.vote_shade = r->vote_shade; fp.vote_dir = r->vote_dir; fp.vote_spec = r->vote_spec; fp.vote_tail_node = r->vote_tail_node; fp.vote_tail_shade = r->vote_tail_shade;
+    fp.vote_node = r->vote_node; fp.vote_shade = r->vote_shade; fp.vote_dir = r->vote_dir; fp.vote_spec = r->vote_spec; fp.frames_in_flight = r->frames_in_flight; fp.vote_tail_node = r->vote_tail_node; fp.vote_tail_shade = r->vote_tail_shade;
 }
 
 static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_scene *scene, uint32_t n_frames,

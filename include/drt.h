@@ -192,6 +192,10 @@ int           drt_renderer_set_stream(drt_renderer *r, void *hip_stream);     /*
 int           drt_renderer_set_counting(drt_renderer *r, int32_t enable);     /* exact work counters (slower kernel) */
 int           drt_renderer_get_counters(drt_renderer *r, drt_counters *out);
 int           drt_renderer_kernel_info(const drt_renderer *r, char *buf, size_t cap);  /* name/variant of the last kernel */
+/* Hint: the caller keeps n launches in flight on this device (several renderers, each on its own stream, driven through
+ * drt_renderer_render_batch_async).  Small launches are then given fewer workgroups so that they overlap instead of
+ * queueing behind each other.  Default 1 = every launch sized to fill the GPU on its own.  Results do not depend on it. */
+int           drt_renderer_set_frames_in_flight(drt_renderer *r, int32_t n);
 /* Execution time of the tracing kernel(s) of the last batch that drt_renderer_wait / a blocking render completed, as
  * the kernel itself measured it (first wave in .. last wave out on the device's constant-rate clock).  Unlike the stream
  * events behind *delta_ms it does not include time the launch spent queued behind other streams' work.  0 for the
