@@ -29,7 +29,8 @@ struct Error : std::runtime_error {
 inline void check(int rc) { if (rc < 0) throw Error(rc, drt_last_error()); }
 }  // namespace drt
 
-struct float3_ { float x, y, z; };      // stand-in for CUDA's float3 in this header's public fields
+struct float2_ { float x, y; };         // stand-ins for CUDA's vector types in this header's public fields
+struct float3_ { float x, y, z; };
 struct float4_ { float x, y, z, w; };
 
 // Core/Scene/RendererSettings.h:4-35
@@ -43,7 +44,7 @@ struct RendererSettings {
     int ray_bounce_limit = 2;
     RenderModes RenderMode = RenderModes::NORMALMODE;
     DebugModes DebugMode = DebugModes::ALBEDO_DEBUG;
-    float sunlight_dir[2] = { -0.803f, 0.681f };
+    float2_ sunlight_dir = { -0.803f, 0.681f };
     float3_ sunlight_color = { 1.000f, 0.944f, 0.917f };
     float sunlight_intensity = 30;
     float3_ sky_color = { 0.25f, 0.498f, 0.80f };
@@ -54,7 +55,7 @@ struct RendererSettings {
         s.gamma_correction = gamma_correction; s.tone_mapping = tone_mapping; s.enable_sunlight = enableSunlight;
         s.max_samples = max_samples; s.ray_bounce_limit = ray_bounce_limit;
         s.render_mode = (int)RenderMode; s.debug_mode = (int)DebugMode;
-        s.sunlight_dir[0] = sunlight_dir[0]; s.sunlight_dir[1] = sunlight_dir[1];
+        s.sunlight_dir[0] = sunlight_dir.x; s.sunlight_dir[1] = sunlight_dir.y;
         s.sunlight_color[0] = sunlight_color.x; s.sunlight_color[1] = sunlight_color.y; s.sunlight_color[2] = sunlight_color.z;
         s.sunlight_intensity = sunlight_intensity;
         s.sky_color[0] = sky_color.x; s.sky_color[1] = sky_color.y; s.sky_color[2] = sky_color.z;
@@ -102,9 +103,14 @@ private:
     static float3_ cross(float3_ a, float3_ b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
 };
 
+// Core/Scene/Mesh.cuh:8-18 (what the editor's metrics loop reads, EditorLayer.cpp:61-64)
+struct Mesh { const char *name = ""; int m_primitives_offset = -1; size_t m_trisCount = 0; };
+
 // Core/Scene/Scene.cuh:41-57
 struct Scene {
-    Scene() : handle(drt_scene_create()) { if (!handle) throw drt::Error(DRT_ERR_INVALID, drt_last_error()); }
+    Scene() : m_PrimitivesBuffer{ this }, m_BVHNodes{ this }, handle(drt_scene_create()) {
+        if (!handle) throw drt::Error(DRT_ERR_INVALID, drt_last_error());
+    }
     ~Scene() { drt_scene_destroy(handle); }
     Scene(const Scene &) = delete;
     Scene &operator=(const Scene &) = delete;
@@ -112,10 +118,20 @@ struct Scene {
     // strict = true: read the file as the glTF 2.0 specification defines it (drt.h DRT_LOAD_STRICT) instead of as Scene.cu does
     bool loadGLTFmodel(const char *filepath, bool strict = false) {
         drt::check(drt_scene_load_gltf_ex(handle, filepath, strict ? DRT_LOAD_STRICT : 0u));
+        refresh();
         return true;
     }
 
-    // what the editor's metrics panel reads from m_Meshes / m_Material / m_Textures (EditorLayer.cpp:57-65)
+    // host-side copies of what the reference keeps in thrust device vectors; enough for `.size()` and a range-for
+    std::vector<Mesh> m_Meshes;
+    std::vector<drt_material> m_Material;
+    std::vector<drt_texture_info> m_Textures;
+    // m_PrimitivesBuffer / m_BVHNodes live inside the scene handle; these members only name them, so that
+    // `scene.d_BVHTreeRoot = builder.buildIterative(scene.m_PrimitivesBuffer, scene.m_BVHNodes)` (EditorLayer.cpp:55) compiles
+    struct Part { Scene *scene; };
+    Part m_PrimitivesBuffer, m_BVHNodes;
+    const void *d_BVHTreeRoot = nullptr;              // non-null once a BVH has been built
+
     size_t meshCount() const { return (size_t)drt_scene_mesh_count(handle); }
     size_t trianglesCount() const { return (size_t)drt_scene_triangle_count(handle); }
     size_t materialsCount() const { return (size_t)drt_scene_material_count(handle); }
@@ -130,6 +146,16 @@ struct Scene {
         if (!v.empty()) drt::check(drt_scene_get_nodes(handle, v.data(), (int32_t)v.size()));
         return v;
     }
+    void refresh() {                                                      // after anything that changes the scene
+        std::vector<drt_mesh> meshes(meshCount());
+        if (!meshes.empty()) drt::check(drt_scene_get_meshes(handle, meshes.data(), (int32_t)meshes.size()));
+        m_Meshes.clear();
+        for (const drt_mesh &m : meshes) { Mesh out; out.m_primitives_offset = m.primitives_offset; out.m_trisCount = (size_t)m.tris_count; m_Meshes.push_back(out); }
+        m_Material.resize(materialsCount());
+        if (!m_Material.empty()) drt::check(drt_scene_get_materials(handle, m_Material.data(), (int32_t)m_Material.size()));
+        m_Textures.resize(texturesCount());
+        for (size_t i = 0; i < m_Textures.size(); i++) drt::check(drt_scene_get_texture_info(handle, (int32_t)i, &m_Textures[i]));
+    }
 
     drt_scene *handle;
 };
@@ -141,8 +167,18 @@ public:
     int m_TargetLeafPrimitivesCount = 6;
     // the reference passes (scene.m_PrimitivesBuffer, scene.m_BVHNodes) and stores the returned root pointer
     // (EditorLayer.cpp:55); here the scene owns both, so the scene is the argument.
-    void buildIterative(Scene &scene) { drt::check(drt_scene_build_bvh(scene.handle, m_TargetLeafPrimitivesCount, m_BinCount)); }
+    void buildIterative(Scene &scene) {
+        drt::check(drt_scene_build_bvh(scene.handle, m_TargetLeafPrimitivesCount, m_BinCount));
+        scene.d_BVHTreeRoot = scene.handle;
+    }
     void build(Scene &scene) { buildIterative(scene); }                   // BVHBuilder.cu:100-173: same tree via recursion
+    // the reference's spelling (EditorLayer.cpp:55): both arguments name parts of one scene; returns the root token
+    const void *buildIterative(Scene::Part &primitives, Scene::Part &nodes) {
+        if (primitives.scene != nodes.scene) throw drt::Error(DRT_ERR_INVALID, "primitives and nodes of different scenes");
+        buildIterative(*primitives.scene);
+        return primitives.scene->d_BVHTreeRoot;
+    }
+    const void *build(Scene::Part &primitives, Scene::Part &nodes) { return buildIterative(primitives, nodes); }
 };
 
 // Core/Renderer.hpp:14-47

@@ -156,7 +156,7 @@ int main() {
     kv("settings.gamma_correction", rs.gamma_correction); kv("settings.tone_mapping", rs.tone_mapping); kv("settings.enableSunlight", rs.enableSunlight);
     kv("settings.max_samples", rs.max_samples); kv("settings.ray_bounce_limit", rs.ray_bounce_limit);
     kv("settings.RenderMode", (int)rs.RenderMode); kv("settings.DebugMode", (int)rs.DebugMode);
-    kf("settings.sunlight_dir.x", rs.sunlight_dir[0]); kf("settings.sunlight_dir.y", rs.sunlight_dir[1]);
+    kf("settings.sunlight_dir.x", rs.sunlight_dir.x); kf("settings.sunlight_dir.y", rs.sunlight_dir.y);
     kf("settings.sunlight_color.x", rs.sunlight_color.x); kf("settings.sunlight_color.y", rs.sunlight_color.y); kf("settings.sunlight_color.z", rs.sunlight_color.z);
     kf("settings.sunlight_intensity", rs.sunlight_intensity);
     kf("settings.sky_color.x", rs.sky_color.x); kf("settings.sky_color.y", rs.sky_color.y); kf("settings.sky_color.z", rs.sky_color.z);
@@ -181,3 +181,28 @@ int main() {
     assert len(ours) == 35
     for k, v in ours.items():
         assert int(v) == ref[k], (k, v, ref[k])
+
+
+def _build_editor_calls(tmp_path):
+    exe = tmp_path / "editor_calls"
+    lib_dir = os.path.dirname(drt.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "editor_calls.cpp"),
+                    "-L" + lib_dir, "-ldrt_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    return exe
+
+
+def test_editor_statements_compile_against_the_wrapper(tmp_path):
+    """tests/cpp/editor_calls.cpp repeats the statements Editor/EditorLayer.cpp makes on Scene / BVHBuilder / Camera /
+    RendererSettings / Renderer (member names, argument types, the buildIterative(m_PrimitivesBuffer, m_BVHNodes) spelling,
+    addresses of settings members for the widgets): it must compile warning-free, and its scene / camera part must run."""
+    exe = _build_editor_calls(tmp_path)
+    out = subprocess.run([str(exe), os.path.join(ROOT, "models", "cs16_dust.glb")], capture_output=True, text=True, check=True).stdout
+    assert "objects=1 triangles=11167 materials=23 textures=23 root=1" in out     # the editor's metrics panel (SURVEY appendix A)
+    assert "settings: 0 1 1 2 500 0.944 30.0 -0.803 0.681 0.800 20.0 | 1.0472 10.0 0.0 1.0" in out
+
+
+@pytest.mark.gpu
+def test_editor_statements_render(tmp_path):
+    exe = _build_editor_calls(tmp_path)
+    out = subprocess.run([str(exe), os.path.join(ROOT, "models", "cornell_box.glb"), "--render"], capture_output=True, text=True, check=True).stdout
+    assert "rendered 160 x 90, sample 2" in out
