@@ -626,9 +626,15 @@ hipError_t launch_one(const SceneView &sc, const FrameParams &fp, unsigned int *
     // enough to amortise their fill and drain, and the other launches find free CU slots instead of queueing behind a
     // full-size grid (1/8 shard, 3 frames in flight: 0.60 -> 0.57 ms per step; a whole frame still gets every slot).
     // A launch that has the GPU to itself wants every slot it can fill: 4 chunks (one per wave) per workgroup.
+    // (the grid never drops below this launch's fair share of the GPU, slots / frames in flight: tiny launches must not
+    // leave the machine empty)
     static const uint64_t chunks_per_wg_env = std::getenv("DRT_CHUNKS_PER_WG") ? (uint64_t)std::max(1, std::atoi(std::getenv("DRT_CHUNKS_PER_WG"))) : 0;
-    const uint64_t chunks_per_wg = chunks_per_wg_env ? chunks_per_wg_env : (fp.frames_in_flight > 1 ? 64 : 4);
-    const int blocks = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)num_cus * per_cu_cache, (n_chunks + chunks_per_wg - 1) / chunks_per_wg));
+    const uint64_t slots = (uint64_t)num_cus * per_cu_cache;
+    uint64_t want = std::min<uint64_t>(slots, (n_chunks + 3) / 4);                       // at least one chunk per wave
+    if (chunks_per_wg_env) want = std::min<uint64_t>(want, (n_chunks + chunks_per_wg_env - 1) / chunks_per_wg_env);
+    else if (fp.frames_in_flight > 1)
+        want = std::min<uint64_t>(want, std::max<uint64_t>((n_chunks + 63) / 64, slots / (uint64_t)fp.frames_in_flight));
+    const int blocks = (int)std::max<uint64_t>(1, want);
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), lds_bytes, stream, sc, fp, chunk_counter, (uint32_t)n_chunks, tiles_x, samples, stack_entries);
     return hipGetLastError();
 }
