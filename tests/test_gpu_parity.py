@@ -520,3 +520,31 @@ def test_randomised_cases_match_oracle():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "250", "31"], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatching 0" in r.stdout
+
+
+def test_bench_line_has_the_contracted_shape():
+    """bench.py prints ONE JSON line with the keys the driver reads, the roofline and cpu_baseline objects included."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.scenes import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key, kind in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                      ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[key], kind), key
+    assert d["metric"].startswith("Msamples/sec at 1920x1080, 8spp, cornell_box") and d["unit"] == "Msamples/s"
+    assert (d["n_gpus"], d["steps"], d["warmup"], d["higher_is_better"], d["scaling"], d["vs_baseline"], d["dtype"]) == (1, 6, 2, True, "strong", None, "f32")
+    assert d["config"]["workload"] == "cornell_box_1080p_8spp_d8" and "model" not in d["config"]
+    assert abs(d["value"] - 1920 * 1080 * 8 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+    roof = d["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["kernel_ms"] > 0
+    assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["kernel_ms"] * 1e-3) / 1e9) < 0.01 * roof["achieved"]
+    cpu = d["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["unit"] == "Msamples/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and "samples" in cpu["sample"]
