@@ -548,3 +548,22 @@ def test_bench_line_has_the_contracted_shape():
     assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["kernel_ms"] * 1e-3) / 1e9) < 0.01 * roof["achieved"]
     cpu = d["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["unit"] == "Msamples/s" and cpu["value"] > 0 and cpu["cores"] >= 1 and "samples" in cpu["sample"]
+
+
+def test_bench_two_rank_rehearsal_assembles_the_single_device_image():
+    """The multi-GPU code path of bench.py on the one-GPU box: two ranks (torch.distributed.run), both on device 0, stripes
+    gathered through gloo (RCCL refuses two ranks on one device) and assembled on rank 0 -- the result must be the
+    single-device image, bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.scenes import ROOT
+    env = dict(os.environ, DRT_BENCH_REHEARSAL="1", DRT_BENCH_CHECK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "sharded image == single-device image: True" in r.stderr
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "stripes8x2" and "REHEARSAL" in d["data"]
