@@ -44,6 +44,9 @@ namespace drt {
 namespace {
 
 constexpr int kThreads = 256;
+#ifndef DRT_PRIO_S
+#define DRT_PRIO_S 1
+#endif
 #ifndef DRT_TRIS_PER_STEP
 #define DRT_TRIS_PER_STEP 2
 #endif
@@ -253,6 +256,9 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
         const int n_s = __popcll(m_s);
         if (n_s >= vote_shade || (m_t == 0 && m_n == 0 && n_s > 0 && n_s >= __popcll(m_r))) {
             if (COUNT) { d_exec[2]++; d_lanes[2] += (unsigned long long)n_s; d_t0 = __builtin_amdgcn_s_memtime(); }
+            // S is the long, memory-latency-bound phase (material / texel chains): a wave inside it goes first, so its loads
+            // are issued early and it is back in the compute phases sooner (+1-2 %, tools/ab_libs.py)
+            __builtin_amdgcn_s_setprio(DRT_PRIO_S);
             const bool in_s = !(cur < end) && !(sp > 0) && !(stage == kNeedDir && spec >= 0) && stage != kFinished;
             // Lean paths gather light only where they end (the sky term below), in the S run that also stores the
             // sample: the running sum is zero on entry, and resetting it here frees its registers between S runs.
@@ -404,6 +410,7 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
             m_sp = ballot(sp > 0);
             m_dir = ballot(stage == kNeedDir && spec >= 0); m_fin = ballot(stage == kFinished);
             m_pend = ballot(spec > 0);
+            __builtin_amdgcn_s_setprio(0);
             if (COUNT) d_time[2] += __builtin_amdgcn_s_memtime() - d_t0;
         }
 
@@ -434,6 +441,7 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
             if (n_n == 0) break;
             if (n_n < vote_node && m_t != 0) break;
             if (COUNT) { d_exec[1]++; d_lanes[1] += (unsigned long long)n_n; d_t0 = __builtin_amdgcn_s_memtime(); }
+
             if (!(cur < end) && sp > 0) {
                 --sp;
                 const StackEntry e = stack[sp][tid];
