@@ -187,6 +187,7 @@ _sig("drt_scene_set_geometry", C.c_int, _P, _P, _P, _P, _P, C.c_int32)
 _sig("drt_scene_add_material", C.c_int, _P, C.POINTER(C.c_float), C.c_int32)
 _sig("drt_scene_add_texture", C.c_int, _P, _P, C.c_int32, C.c_int32, C.c_int32)
 _sig("drt_scene_build_bvh", C.c_int, _P, C.c_int32, C.c_int32)
+_sig("drt_scene_build_bvh_device", C.c_int, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float))
 for _n in ("triangle", "node", "material", "texture", "mesh"):
     _sig("drt_scene_%s_count" % _n, C.c_int32, _P)
 _sig("drt_scene_bvh_depth", C.c_int32, _P)
@@ -331,9 +332,16 @@ class BVHBuilder:
     def __init__(self):
         self.m_BinCount = 8
         self.m_TargetLeafPrimitivesCount = 6
+        self.m_BuildDevice = -1          # new: >= 0 builds the same tree on that GPU (drt_scene_build_bvh_device)
+        self.m_LastBuildDeviceMs = 0.0
 
     def buildIterative(self, scene):
-        _check(_lib.drt_scene_build_bvh(scene._h, self.m_TargetLeafPrimitivesCount, self.m_BinCount))
+        if self.m_BuildDevice >= 0:
+            ms = C.c_float(0)
+            _check(_lib.drt_scene_build_bvh_device(scene._h, self.m_TargetLeafPrimitivesCount, self.m_BinCount, self.m_BuildDevice, C.byref(ms)))
+            self.m_LastBuildDeviceMs = ms.value
+        else:
+            _check(_lib.drt_scene_build_bvh(scene._h, self.m_TargetLeafPrimitivesCount, self.m_BinCount))
         return scene
 
     build = buildIterative      # BVHBuilder.cu:100-173 produces the same tree through recursion

@@ -19,6 +19,7 @@
 #include "device_scene.hpp"
 #include "render_kernels.hpp"
 #include "scene_host.hpp"
+#include "bvh_build_device.hpp"
 #include "png_decode.hpp"
 
 using namespace drt;
@@ -38,6 +39,7 @@ int from_exception() {
     } catch (const UnsupportedError &e) { return fail(DRT_ERR_UNSUPPORTED, e.what());
     } catch (const IoError &e) { return fail(DRT_ERR_IO, e.what());
     } catch (const BvhError &e) { return fail(DRT_ERR_BVH, e.what());
+    } catch (const DeviceError &e) { return fail(DRT_ERR_DEVICE, e.what());
     } catch (const std::invalid_argument &e) { return fail(DRT_ERR_INVALID, e.what());
     } catch (const std::bad_alloc &) { return fail(DRT_ERR_INVALID, "out of host memory");
     } catch (const std::exception &e) { return fail(DRT_ERR_PARSE, e.what());
@@ -217,6 +219,16 @@ int drt_scene_add_texture(drt_scene *s, const uint8_t *texels, int32_t width, in
 int drt_scene_build_bvh(drt_scene *s, int32_t target_leaf_prims, int32_t bin_count) {
     if (!s) return fail(DRT_ERR_INVALID, "null scene");
     try { s->host.build_bvh(target_leaf_prims, bin_count); return DRT_OK; } catch (...) { return from_exception(); }
+}
+
+int drt_scene_build_bvh_device(drt_scene *s, int32_t target_leaf_prims, int32_t bin_count, int32_t device, float *build_ms) {
+    if (!s) return fail(DRT_ERR_INVALID, "null scene");
+    if (build_ms) *build_ms = 0.f;
+    try {
+        const float ms = s->host.build_bvh_on_device(target_leaf_prims, bin_count, device);
+        if (build_ms) *build_ms = ms;
+        return DRT_OK;
+    } catch (...) { return from_exception(); }
 }
 
 int32_t drt_scene_triangle_count(const drt_scene *s) { return s ? (int32_t)s->host.triangles.size() : 0; }

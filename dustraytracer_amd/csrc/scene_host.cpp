@@ -7,6 +7,7 @@
 // Compile with -ffp-contract=off: every product and sum below rounds on its own, like the reference's
 // host code built without FMA.
 #include "scene_host.hpp"
+#include "bvh_build_device.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -667,6 +668,21 @@ void HostScene::build_bvh(int32_t target_leaf_prims, int32_t bin_count) {
     out.push_back(root);
     triangles.swap(work);
     nodes.swap(out);
+}
+
+float HostScene::build_bvh_on_device(int32_t target_leaf_prims, int32_t bin_count, int device) {
+    if (bin_count < 2) throw std::invalid_argument("bin_count must be >= 2");
+    if ((int64_t)triangles.size() <= (int64_t)target_leaf_prims) {      // one leaf (BVHBuilder.cu:34-43): nothing to do in parallel
+        build_bvh(target_leaf_prims, bin_count);
+        return 0.f;
+    }
+    DeviceBuild built = drt::build_bvh_on_device(triangles, target_leaf_prims, bin_count, device);
+    std::vector<drt_triangle> reordered(triangles.size());
+    for (size_t i = 0; i < reordered.size(); i++) reordered[i] = triangles[built.order[i]];
+    triangles.swap(reordered);
+    nodes.swap(built.nodes);
+    revision = next_revision();
+    return built.device_ms;
 }
 
 int32_t HostScene::bvh_depth() const {

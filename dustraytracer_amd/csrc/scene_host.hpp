@@ -44,6 +44,8 @@ public:
     void load_gltf(const char *path, bool strict = false);        // throws std::runtime_error / UnsupportedError
     void set_geometry(const float *pos, const float *nrm, const float *uv, const int32_t *mat, int32_t n_tris);
     void build_bvh(int32_t target_leaf_prims, int32_t bin_count);   // throws BvhError when the reference would hang
+    // The same tree built on a GPU (kernel_bvh_build.hip); returns the device time in ms.  Throws DeviceError without one.
+    float build_bvh_on_device(int32_t target_leaf_prims, int32_t bin_count, int device);
     int32_t bvh_depth() const;
 
     // Device-layout image of the scene (see device_scene.hpp); throws when there is no BVH.

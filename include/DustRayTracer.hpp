@@ -165,10 +165,15 @@ class BVHBuilder {
 public:
     int m_BinCount = 8;
     int m_TargetLeafPrimitivesCount = 6;
+    int m_BuildDevice = -1;               // new: >= 0 runs the same build on that GPU (drt_scene_build_bvh_device)
+    float m_LastBuildDeviceMs = 0;
     // the reference passes (scene.m_PrimitivesBuffer, scene.m_BVHNodes) and stores the returned root pointer
     // (EditorLayer.cpp:55); here the scene owns both, so the scene is the argument.
     void buildIterative(Scene &scene) {
-        drt::check(drt_scene_build_bvh(scene.handle, m_TargetLeafPrimitivesCount, m_BinCount));
+        if (m_BuildDevice >= 0)
+            drt::check(drt_scene_build_bvh_device(scene.handle, m_TargetLeafPrimitivesCount, m_BinCount, m_BuildDevice, &m_LastBuildDeviceMs));
+        else
+            drt::check(drt_scene_build_bvh(scene.handle, m_TargetLeafPrimitivesCount, m_BinCount));
         scene.d_BVHTreeRoot = scene.handle;
     }
     void build(Scene &scene) { buildIterative(scene); }                   // BVHBuilder.cu:100-173: same tree via recursion

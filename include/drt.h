@@ -141,6 +141,9 @@ int        drt_scene_set_geometry(drt_scene *s, const float *positions, const fl
 int        drt_scene_add_material(drt_scene *s, const float albedo[3], int32_t albedo_tex);
 int        drt_scene_add_texture(drt_scene *s, const uint8_t *texels, int32_t width, int32_t height, int32_t components);
 int        drt_scene_build_bvh(drt_scene *s, int32_t target_leaf_prims, int32_t bin_count);  /* BVHBuilder::buildIterative */
+/* The same build run on GPU `device`: identical nodes, node order and triangle order -- a bound that
+ * is a zero may carry the other sign.  build_ms (may be NULL) receives the device time.  DRT_ERR_DEVICE without a GPU. */
+int        drt_scene_build_bvh_device(drt_scene *s, int32_t target_leaf_prims, int32_t bin_count, int32_t device, float *build_ms);
 int32_t    drt_scene_triangle_count(const drt_scene *s);                      /* m_PrimitivesBuffer.size() */
 int32_t    drt_scene_node_count(const drt_scene *s);                          /* m_BVHNodes.size() */
 int32_t    drt_scene_material_count(const drt_scene *s);

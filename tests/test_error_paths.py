@@ -68,6 +68,13 @@ def test_without_a_gpu_the_renderer_refuses_to_exist():
         drt.Renderer(0)
     assert e.value.code == drt.ERR_DEVICE
     assert drt._lib.drt_renderer_create(0) in (None, 0)
+    sc = drt.Scene()
+    sc.loadGLTFmodel(scene_path("room"))
+    b = drt.BVHBuilder()
+    b.m_BuildDevice = 0                                          # the GPU builder does not quietly run the host one either
+    with pytest.raises(drt.DrtError) as e:
+        b.buildIterative(sc)
+    assert e.value.code == drt.ERR_DEVICE and len(sc.m_BVHNodes) == 0
 
 
 @pytest.mark.gpu
