@@ -454,9 +454,7 @@ DeviceBuild build_bvh_on_device(const std::vector<drt_triangle> &tris, int32_t l
         level_begin.push_back(c.n_nodes);
         n_active = c.n_active_next; n_chunks = c.n_chunks_next;
         if (n_active > max_active || n_chunks > max_chunks) throw BvhError("internal: level larger than its bound");
-        const Counters reset{ c.n_nodes, 0, 0, 0 };
-        check(hipMemcpyAsync(d_counters, &reset, sizeof reset, hipMemcpyHostToDevice, stream), "hipMemcpy (counters)");
-        check(hipStreamSynchronize(stream), "BVH build level");
+        check(hipMemsetAsync(&d_counters->n_active_next, 0, 2 * sizeof(uint32_t), stream), "hipMemset (counters)");   // stream-ordered: no second sync
         cur ^= 1;
     }
     if (error & 1u)
