@@ -43,8 +43,12 @@ def _file_scene(name):
 
 def _soup(n, seed, clustered=False):
     rng = np.random.default_rng(seed)
-    centre = rng.uniform(-10, 10, (n, 1, 3)) if not clustered else rng.normal(0, 1, (n, 1, 3)) ** 3
-    pos = (centre + rng.uniform(-0.2, 0.2, (n, 3, 3))).astype(np.float32)
+    centre = rng.uniform(-10, 10, (n, 1, 3))
+    size = 0.2
+    if clustered:                                   # half of the triangles in a tight cluster: deep, unbalanced tree
+        centre[: n // 2] = rng.normal(0, 0.5, (n // 2, 1, 3)) + 3.0
+        size = 0.02
+    pos = (centre + rng.uniform(-size, size, (n, 3, 3))).astype(np.float32)
     nrm = np.tile(np.array([0, 1, 0], np.float32), (n, 3, 1))
     uv = np.zeros((n, 3, 2), np.float32)
     mat = np.zeros(n, np.int32)

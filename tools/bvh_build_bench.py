@@ -1,7 +1,7 @@
 """Host vs GPU BVH build time (same tree): shipped scenes and synthetic soups.  Run on the GPU box."""
-import sys, time
+import os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dustraytracer_amd as drt
 from tests.scenes import scene_path
 

@@ -31,4 +31,8 @@ for wl in suzanne_plane_1080p_8spp_d2 dense_monkey_1080p_16spp_d2 cs16_dust_1080
 done
 python3 $R/bench.py --workload room_4k_64spp_d16 --cpu-seconds 3 --steps 3 --warmup 1 > $O/bench_room_4k_64spp_d16.json
 for s in 0/2 0/4 0/8; do python3 $R/bench.py --emulate-shard $s --cpu-seconds 0 --steps 200 --warmup 20 > $O/bench_shard_${s/\//of}.json; done
+# 6. BVH build on the device: host vs GPU table, and the per-kernel times of the same command
+cd $R && python3 tools/bvh_build_bench.py > $O/bvh_build_host_vs_gpu.txt 2> /dev/null
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bvh -o bvh -- python3 $R/tools/bvh_build_bench.py > /dev/null 2> /tmp/p_bvh.log
+cp /tmp/p_bvh/bvh_kernel_stats.csv $O/bvh_build_kernel_stats.csv
 ls -la $O

@@ -8,7 +8,8 @@ plain = {"bench_default.json": "%s_bench_default.json", "bench_default_under_roc
          "bench_default_f3_kernel_stats.csv": "%s_bench_default_f3_kernel_stats.csv",
          "bench_f1_under_rocprof.json": "%s_bench_f1_isolated.json", "bench_f1_isolated_kernel_stats.csv": "%s_bench_f1_isolated_kernel_stats.csv",
          "wave_queue_pmc_sq.txt": "%s_wave_queue_pmc_sq.txt", "phase_stats_cornell.txt": "%s_phase_stats_cornell.txt",
-         "phase_stats_cs16_dust.txt": "%s_phase_stats_cs16_dust.txt"}
+         "phase_stats_cs16_dust.txt": "%s_phase_stats_cs16_dust.txt",
+         "bvh_build_host_vs_gpu.txt": "%s_bvh_build_host_vs_gpu.txt", "bvh_build_kernel_stats.csv": "%s_bvh_build_kernel_stats.csv"}
 for a, b in plain.items():
     shutil.copy(os.path.join(src, a), os.path.join(dst, b % tag))
 for f in glob.glob(os.path.join(src, "traffic_*.json")):
