@@ -102,6 +102,7 @@ struct drt_renderer {
     bool use_pixel_walk = false;              // DRT_KERNEL=pixel_walk selects the first (non-persistent) kernel
     bool scene_has_alpha = false;
     int vote_node = 12, vote_shade = 36, vote_dir = 4, vote_spec = 8;
+    int leaf_chain = -1;                              // DRT_LEAF_CHAIN: -1 = by tree depth (<= 4 levels), 0 / 1 = forced
     int vote_tail_node = 4, vote_tail_shade = 36;    // once the queue is empty (DRT_VOTE_TN / DRT_VOTE_TS): pops stop waiting for company   // wave_queue phase-voting thresholds (DRT_VOTE_N/S/R/P override)
     const char *kernel_name = "";
     int launch_shape[3] = { 0, 0, 0 };       // wave_queue: stack slots per lane, workgroups per CU, LDS KiB per workgroup
@@ -309,6 +310,7 @@ drt_renderer *drt_renderer_create(int32_t device) {
     r->vote_spec = std::max(1, env_int("DRT_VOTE_P", r->vote_spec));
     r->vote_tail_node = std::max(1, env_int("DRT_VOTE_TN", r->vote_tail_node));
     r->vote_tail_shade = std::max(1, env_int("DRT_VOTE_TS", r->vote_tail_shade));
+    r->leaf_chain = env_int("DRT_LEAF_CHAIN", r->leaf_chain);
     r->sample_budget = (size_t)std::max(1, env_int("DRT_SAMPLE_MB", 1024)) << 20;
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) r->num_cus = cus;
@@ -535,6 +537,7 @@ static void fill_frame_params(const drt_renderer *r, const drt_camera *cam, Fram
     fp.accum = r->cur_accum(); fp.rgba = r->cur_rgba();
     fp.counters = r->counting ? r->counters : nullptr;
     fp.vote_node = r->vote_node; fp.vote_shade = r->vote_shade; fp.vote_dir = r->vote_dir; fp.vote_spec = r->vote_spec; fp.frames_in_flight = r->frames_in_flight; fp.vote_tail_node = r->vote_tail_node; fp.vote_tail_shade = r->vote_tail_shade;
+    fp.leaf_chain = r->leaf_chain < 0 ? (r->bvh_depth <= 4 ? 1 : 0) : (r->leaf_chain != 0);
 }
 
 static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_scene *scene, uint32_t n_frames,
