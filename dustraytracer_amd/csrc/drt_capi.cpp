@@ -101,7 +101,7 @@ struct drt_renderer {
     int frames_in_flight = 1;                 // drt_renderer_set_frames_in_flight
     bool use_pixel_walk = false;              // DRT_KERNEL=pixel_walk selects the first (non-persistent) kernel
     bool scene_has_alpha = false;
-    int vote_node = 12, vote_shade = 36, vote_dir = 4, vote_spec = 8;
+    int vote_node = 12, vote_shade = 44, vote_dir = 4, vote_spec = 8;
     int leaf_chain = -1;                              // DRT_LEAF_CHAIN: -1 = by tree depth (<= 4 levels), 0 / 1 = forced
     int vote_tail_node = 4, vote_tail_shade = 36;    // once the queue is empty (DRT_VOTE_TN / DRT_VOTE_TS): pops stop waiting for company   // wave_queue phase-voting thresholds (DRT_VOTE_N/S/R/P override)
     const char *kernel_name = "";
