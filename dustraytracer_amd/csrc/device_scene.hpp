@@ -103,6 +103,7 @@ struct FrameParams {
     int32_t frames_in_flight;         // launches the caller keeps in flight on this device (grid sizing of small launches)
     int32_t vote_tail_node, vote_tail_shade;   // thresholds once the sample queue is empty (drain of the launch)
     int32_t leaf_chain;                        // T steps take the next leaf off the stack themselves (shallow trees)
+    uint32_t row_step;                         // wave_queue work order: stride over the tile rows, coprime to their number
 };
 
 }  // namespace drt

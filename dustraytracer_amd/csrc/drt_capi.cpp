@@ -537,6 +537,16 @@ static void fill_frame_params(const drt_renderer *r, const drt_camera *cam, Fram
     fp.accum = r->cur_accum(); fp.rgba = r->cur_rgba();
     fp.counters = r->counting ? r->counters : nullptr;
     fp.vote_node = r->vote_node; fp.vote_shade = r->vote_shade; fp.vote_dir = r->vote_dir; fp.vote_spec = r->vote_spec; fp.frames_in_flight = r->frames_in_flight; fp.vote_tail_node = r->vote_tail_node; fp.vote_tail_shade = r->vote_tail_shade;
+    {   // tile rows are visited with a golden-ratio stride (kernel_wave_queue.hip, DRT_CHUNK_ORDER)
+        const uint32_t tiles_y = (r->local_rows + 7) / 8;
+        uint32_t step = 1;
+        if (tiles_y > 2 && tiles_y < 65536) {
+            step = std::max<uint32_t>(1, (uint32_t)(0.6180339887 * tiles_y + 0.5));
+            auto gcd = [](uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; };
+            while (gcd(step, tiles_y) != 1) step++;
+        }
+        fp.row_step = step;
+    }
     fp.leaf_chain = r->leaf_chain < 0 ? (r->bvh_depth <= 4 ? 1 : 0) : (r->leaf_chain != 0);
 }
 

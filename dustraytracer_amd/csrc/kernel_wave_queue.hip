@@ -381,8 +381,20 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
             }
             // (e) primary ray of the new sample  RayGen.cuh:63-86
             if (got) {
-                const uint32_t tile = my_chunk / fp.n_frames, f_rel = my_chunk - tile * fp.n_frames;
-                const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+#ifndef DRT_CHUNK_ORDER
+#define DRT_CHUNK_ORDER 4
+#endif
+                // chunk -> (tile, frame).  4: frame-major, tile rows visited with a stride (fp.row_step, coprime to the number of
+                // tile rows): at any moment the resident waves work on tile rows from all over the image, so the mix of long
+                // paths (VALU work) and short ones (sky: latency) is the image's average from the first chunk to the last.
+                // 0: tile-major raster; 1: frame-major raster; 5: tile-major with the row stride  (tools/ab_chunk_order.sh)
+                const uint32_t n_tiles_all = n_chunks / fp.n_frames;
+                uint32_t tile, f_rel;
+                if (DRT_CHUNK_ORDER == 1 || DRT_CHUNK_ORDER == 4) { f_rel = my_chunk / n_tiles_all; tile = my_chunk - f_rel * n_tiles_all; }
+                else { tile = my_chunk / fp.n_frames; f_rel = my_chunk - tile * fp.n_frames; }
+                uint32_t ty = tile / tiles_x;
+                const uint32_t tx = tile - ty * tiles_x;
+                if (DRT_CHUNK_ORDER >= 4) ty = (ty * fp.row_step) % (n_tiles_all / tiles_x);
                 const uint32_t x = tx * 8u + (my_k & 7u), ly = ty * 8u + (my_k >> 3);
                 if (x < fp.width && ly < fp.local_rows) {
                     const uint32_t y = ((ly / fp.stripe_rows) * fp.world + fp.rank) * fp.stripe_rows + (ly % fp.stripe_rows);
