@@ -105,7 +105,7 @@ struct drt_renderer {
     int leaf_chain = -1;                              // DRT_LEAF_CHAIN: -1 = by tree depth (<= 4 levels), 0 / 1 = forced
     int vote_tail_node = 4, vote_tail_shade = 36;    // once the queue is empty (DRT_VOTE_TN / DRT_VOTE_TS): pops stop waiting for company   // wave_queue phase-voting thresholds (DRT_VOTE_N/S/R/P override)
     const char *kernel_name = "";
-    int launch_shape[3] = { 0, 0, 0 };       // wave_queue: stack slots per lane, workgroups per CU, LDS KiB per workgroup
+    int launch_shape[4] = { 0, 0, 0, 0 };    // wave_queue: stack slots per lane, workgroups per CU, LDS KiB per workgroup, threads per workgroup
     // device copy of the scene last rendered
     const drt_scene *uploaded_scene = nullptr;
     uint64_t uploaded_revision = 0;
@@ -465,7 +465,8 @@ int drt_renderer_kernel_span(const drt_renderer *r, float *ms) {
 int drt_renderer_kernel_info(const drt_renderer *r, char *buf, size_t cap) {
     if (!r || !buf || cap == 0) return fail(DRT_ERR_INVALID, "bad argument");
     if (r->launch_shape[1] > 0 && std::strncmp(r->kernel_name, "wave_queue", 10) == 0)
-        std::snprintf(buf, cap, "%s stack=%d wg/CU=%d lds=%dKiB", r->kernel_name, r->launch_shape[0], r->launch_shape[1], r->launch_shape[2]);
+        std::snprintf(buf, cap, "%s stack=%d wg/CU=%d%s lds=%dKiB", r->kernel_name, r->launch_shape[0], r->launch_shape[1],
+                      r->launch_shape[3] == 512 ? "x512" : "", r->launch_shape[2]);
     else
         std::snprintf(buf, cap, "%s", r->kernel_name);
     return DRT_OK;

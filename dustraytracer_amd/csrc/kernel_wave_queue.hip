@@ -43,7 +43,8 @@ namespace drt {
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 256;         // workgroup size; kBigThreads where a bigger group shares its LDS scene copy among more waves
+constexpr int kBigThreads = 512;
 #ifndef DRT_PRIO_S
 #define DRT_PRIO_S 1
 #endif
@@ -92,7 +93,7 @@ DRT_DEV int lane_rank(unsigned long long mask) {        // set bits below this l
 #define DRT_OCCUPANCY_ATTR
 #endif
 template <int MODE, bool LDS_SCENE>
-__global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel(const SceneView sc, const FrameParams fp,
+__global__ __launch_bounds__(kBigThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel(const SceneView sc, const FrameParams fp,
                                                               unsigned int *chunk_counter, uint32_t n_chunks, uint32_t tiles_x,
                                                               float4 *samples, uint32_t stack_entries) {
     constexpr bool GENERAL = MODE == 1 || MODE == 2;
@@ -101,24 +102,26 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
     constexpr bool SUN = MODE == 4 || MODE == 5;          // lean + the sun's shadow ray at every hit (RayGen.cuh:124-128)
     constexpr bool SHADOWS = GENERAL || SUN;              // shadow traversals (RayTest, BVHTraversal.cuh:76-134) can occur
     extern __shared__ uint4 lds_raw[];
-    StackEntry(*stack)[kThreads] = reinterpret_cast<StackEntry(*)[kThreads]>(lds_raw);
     const int tid = threadIdx.x;
+    const uint32_t wg = blockDim.x;                                          // 256 or 512 (launch_one)
+    StackEntry *const stack_base = reinterpret_cast<StackEntry *>(lds_raw) + tid;
+#define STACK(level) stack_base[__umul24((uint32_t)(level), wg)]                // entry [level][tid]
     const int lane = tid & 63;
     // The kernel's own execution span (first wave in to last wave out, constant-rate clock): what a profiler reports as
     // the kernel's duration, also when launches from several streams share the GPU and stream events include queueing.
     if (fp.span && lane == 0) atomicMax(&fp.span[0], ~(unsigned long long)wall_clock64());
 
     // ---- scene source: LDS copy (indexed in uint4 units from lds_raw) or HBM ----
-    const uint32_t kSceneBase = stack_entries * (uint32_t)(kThreads * sizeof(StackEntry) / 16);
+    const uint32_t kSceneBase = stack_entries * (wg * (uint32_t)sizeof(StackEntry) / 16u);
     const uint32_t hot_base = kSceneBase + sc.n_inner * 4u;
     const uint32_t leaf_base = hot_base + sc.n_tris * 3u;
     if (LDS_SCENE) {
         const uint4 *g_inner = reinterpret_cast<const uint4 *>(sc.inner);
         const uint4 *g_hot = reinterpret_cast<const uint4 *>(sc.tri_hot);
-        for (uint32_t i = tid; i < sc.n_inner * 4u; i += kThreads) lds_raw[kSceneBase + i] = g_inner[i];
-        for (uint32_t i = tid; i < sc.n_tris * 3u; i += kThreads) lds_raw[hot_base + i] = g_hot[i];
+        for (uint32_t i = tid; i < sc.n_inner * 4u; i += wg) lds_raw[kSceneBase + i] = g_inner[i];
+        for (uint32_t i = tid; i < sc.n_tris * 3u; i += wg) lds_raw[hot_base + i] = g_hot[i];
         LeafRange *l_leaves = reinterpret_cast<LeafRange *>(lds_raw + leaf_base);
-        for (uint32_t i = tid; i < sc.n_leaves; i += kThreads) l_leaves[i] = sc.leaves[i];
+        for (uint32_t i = tid; i < sc.n_leaves; i += wg) l_leaves[i] = sc.leaves[i];
         __syncthreads();
     }
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds_raw);     // low 32 bits of the flat address = LDS offset
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
             // Lean: the pop-time test of BVHTraversal.cuh:38 (-1 < dist < FLT_MAX) can only ever fail for the root -- every
             // other entry was pushed with 0 <= dist < closest -- so it is applied here, once per ray instead of once per pop.
             if (GENERAL || (-1.0f < e.dist && e.dist < FLT_MAX)) {
-                stack[0][tid] = e;
+                STACK(0) = e;
                 sp = 1;
             }
         }
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
                         shadow = true; occluded = false; cur = end = 0; sp = 0;
                         if (sc.root_ref != kNoNode && !(slab_intersect(root_min, root_max, ray) < 0)) {   // BVHTraversal.cuh:95-103
                             StackEntry e; e.ref = sc.root_ref; e.dist = 0;
-                            stack[0][tid] = e;
+                            STACK(0) = e;
                             sp = 1;
                         }
                     }
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
 
             if (!(cur < end) && sp > 0) {
                 --sp;
-                const StackEntry e = stack[sp][tid];
+                const StackEntry e = STACK(sp);
                 bool visit = true;
                 if (!GENERAL) {
                     // :41 (without a hit, hit_t = FLT_MAX > dist); :38 was applied to the root; a shadow traversal has no cull
@@ -480,14 +483,14 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
                         ea.ref = first_is_1 ? c.ref1 : c.ref2; ea.dist = first_is_1 ? d1 : d2;
                         eb.ref = first_is_1 ? c.ref2 : c.ref1; eb.dist = first_is_1 ? d2 : d1;
                         const float limit = SUN && shadow ? FLT_MAX : hit_t;        // RayTest pushes every box it hits (:122-129)
-                        if (ea.dist < limit) { stack[sp][tid] = ea; ++sp; }
+                        if (ea.dist < limit) { STACK(sp) = ea; ++sp; }
                         if (eb.dist < limit) {
                             // A near child that is a leaf goes straight to T: pushed, it would be this lane's next pop, and it would
                             // pass :41 because nothing changes hit_t in between (0 to -5 % on the benchmark scenes)
                             if (eb.ref & kLeafBit) {
                                 const LeafRange leaf = fetch_leaf(eb.ref & ~kLeafBit);
                                 cur = leaf.start; end = leaf.start + leaf.count;
-                            } else { stack[sp][tid] = eb; ++sp; }
+                            } else { STACK(sp) = eb; ++sp; }
                         }
                     } else {
                         const ChildPair c = fetch_children(e.ref);
@@ -501,8 +504,8 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
                         StackEntry e2; e2.ref = c.ref2; e2.dist = d2;
                         const StackEntry ea = first_is_1 ? e1 : e2, eb = first_is_1 ? e2 : e1;
                         const bool pa = first_is_1 ? push1 : push2, pb = first_is_1 ? push2 : push1;
-                        if (pa) { stack[sp][tid] = ea; ++sp; }
-                        if (pb) { stack[sp][tid] = eb; ++sp; }
+                        if (pa) { STACK(sp) = ea; ++sp; }
+                        if (pb) { STACK(sp) = eb; ++sp; }
                     }
                 }
             }
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(kThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel
                     // what the next N step would do for this lane if its top entry is a leaf that survives :41 -- done here, the
                     // lane stays in T.  (A culled leaf or an interior node is left to N.)  Pays on very shallow trees only
                     // (cornell -1.5 %, room +2 %): the host sets fp.leaf_chain by tree depth.
-                    const StackEntry e = stack[sp - 1][tid];
+                    const StackEntry e = STACK(sp - 1);
                     if ((e.ref & kLeafBit) && !((SUN && shadow ? FLT_MAX : hit_t) < e.dist)) {
                         --sp;
                         const LeafRange leaf = fetch_leaf(e.ref & ~kLeafBit);
@@ -639,61 +642,83 @@ __global__ __launch_bounds__(256) void hash_cycles_kernel(uint32_t max_len, uint
 
 template <int MODE, bool LDS_SCENE>
 hipError_t launch_one(const SceneView &sc, const FrameParams &fp, unsigned int *chunk_counter, float4 *samples,
-                      uint32_t stack_entries, size_t lds_bytes, int num_cus, hipStream_t stream, int *blocks_per_cu) {
+                      uint32_t stack_entries, size_t scene_lds_bytes, int num_cus, hipStream_t stream, int *launch_shape) {
     const uint32_t tiles_x = (fp.width + 7) / 8, tiles_y = (fp.local_rows + 7) / 8;
     auto kernel = wave_queue_kernel<MODE, LDS_SCENE>;
+    // Workgroup size.  Every workgroup stages its own copy of an LDS scene next to its lanes' stacks, so a scene of some size
+    // (room: 17.6 KB) is amortised over twice the waves by a 512-thread group: room 4 -> 6 waves per SIMD.  Whichever size
+    // keeps more waves resident wins; 256 on a tie.  (Waves never synchronise after the staging, the size is only packaging.)
+    static int cached_threads = 0, cached_per_cu = 0;          // one set per instantiation
+    static size_t cached_key = ~(size_t)0;
+    const size_t key = scene_lds_bytes * 131u + stack_entries;
+    if (cached_threads == 0 || cached_key != key) {
+        int best_threads = kThreads, best_per_cu = 1, best_waves = 0;
+        for (int threads : { kThreads, kBigThreads }) {
+            if (threads != kThreads && (!LDS_SCENE || scene_lds_bytes < 4096)) continue;
+            const size_t lds = (size_t)stack_entries * threads * sizeof(StackEntry) + scene_lds_bytes;
+            if (lds > 160 * 1024) continue;
+            if (lds > 64 * 1024 &&
+                hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) continue;
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess || n < 1) n = threads == kThreads ? 1 : 0;
+            n = std::min(n, 8 * kThreads / threads);
+            if (n * threads / 64 > best_waves) { best_waves = n * threads / 64; best_threads = threads; best_per_cu = n; }
+        }
+        if (const char *cap = std::getenv("DRT_MAX_BLOCKS_PER_CU")) best_per_cu = std::max(1, std::min(best_per_cu, std::atoi(cap)));
+        if (const char *force = std::getenv("DRT_WG_THREADS")) {       // A/B: force the small group
+            if (std::atoi(force) == kThreads && best_threads != kThreads) {
+                int n = 1;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kThreads, (size_t)stack_entries * kThreads * sizeof(StackEntry) + scene_lds_bytes);
+                best_threads = kThreads; best_per_cu = std::max(1, std::min(n, 8));
+            }
+        }
+        cached_threads = best_threads; cached_per_cu = best_per_cu; cached_key = key;
+    }
+    const int threads = cached_threads, per_cu = cached_per_cu, waves_per_wg = threads / 64;
+    const size_t lds_bytes = (size_t)stack_entries * threads * sizeof(StackEntry) + scene_lds_bytes;
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
+    if (launch_shape) { launch_shape[0] = (int)stack_entries; launch_shape[1] = per_cu; launch_shape[2] = (int)(lds_bytes / 1024); launch_shape[3] = threads; }
     // persistent grid: as many workgroups as the chip keeps resident (registers and LDS decide), never more than
     // there are chunks to hand out.  Workgroups are independent, so a mis-estimate only costs speed.
-    static int per_cu_cache = 0;      // one value per instantiation
-    static size_t per_cu_lds = ~(size_t)0;
-    if (per_cu_cache == 0 || per_cu_lds != lds_bytes) {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kThreads, lds_bytes) != hipSuccess || n < 1) n = 1;
-        per_cu_cache = std::min(n, 8);
-        if (const char *cap = std::getenv("DRT_MAX_BLOCKS_PER_CU")) per_cu_cache = std::max(1, std::min(per_cu_cache, std::atoi(cap)));
-        per_cu_lds = lds_bytes;
-    }
-    if (blocks_per_cu) *blocks_per_cu = per_cu_cache;
     const uint64_t n_chunks = (uint64_t)tiles_x * tiles_y * fp.n_frames;
     if (n_chunks > 0xFFFFFFF0ull) return hipErrorInvalidValue;
     // When the caller keeps several launches in flight (drt_renderer_set_frames_in_flight), a launch with little work -- a
-    // 1/8 shard of a 1080p frame is 32 400 chunks -- gets a smaller grid, about 64 chunks per workgroup: its waves live long
+    // 1/8 shard of a 1080p frame is 32 400 chunks -- gets a smaller grid, about 16 chunks per wave: its waves live long
     // enough to amortise their fill and drain, and the other launches find free CU slots instead of queueing behind a
     // full-size grid (1/8 shard, 3 frames in flight: 0.60 -> 0.57 ms per step; a whole frame still gets every slot).
-    // A launch that has the GPU to itself wants every slot it can fill: 4 chunks (one per wave) per workgroup.
+    // A launch that has the GPU to itself wants every slot it can fill: one chunk per wave.
     // (the grid never drops below this launch's fair share of the GPU, slots / frames in flight: tiny launches must not
     // leave the machine empty)
     static const uint64_t chunks_per_wg_env = std::getenv("DRT_CHUNKS_PER_WG") ? (uint64_t)std::max(1, std::atoi(std::getenv("DRT_CHUNKS_PER_WG"))) : 0;
-    const uint64_t slots = (uint64_t)num_cus * per_cu_cache;
-    uint64_t want = std::min<uint64_t>(slots, (n_chunks + 3) / 4);                       // at least one chunk per wave
+    const uint64_t slots = (uint64_t)num_cus * per_cu;
+    uint64_t want = std::min<uint64_t>(slots, (n_chunks + waves_per_wg - 1) / waves_per_wg);      // at least one chunk per wave
     if (chunks_per_wg_env) want = std::min<uint64_t>(want, (n_chunks + chunks_per_wg_env - 1) / chunks_per_wg_env);
     else if (fp.frames_in_flight > 1)
-        want = std::min<uint64_t>(want, std::max<uint64_t>((n_chunks + 63) / 64, slots / (uint64_t)fp.frames_in_flight));
+        want = std::min<uint64_t>(want, std::max<uint64_t>((n_chunks + 16 * waves_per_wg - 1) / (16 * waves_per_wg), slots / (uint64_t)fp.frames_in_flight));
     const int blocks = (int)std::max<uint64_t>(1, want);
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kThreads), lds_bytes, stream, sc, fp, chunk_counter, (uint32_t)n_chunks, tiles_x, samples, stack_entries);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, stream, sc, fp, chunk_counter, (uint32_t)n_chunks, tiles_x, samples, stack_entries);
     return hipGetLastError();
 }
 
 hipError_t launch_mode(const SceneView &sc, const FrameParams &fp, int mode, bool lds_scene, unsigned int *chunk_counter,
-                       float4 *samples, uint32_t stack_entries, size_t lds_bytes, int num_cus, hipStream_t stream, int *blocks_per_cu) {
+                       float4 *samples, uint32_t stack_entries, size_t scene_lds_bytes, int num_cus, hipStream_t stream, int *launch_shape) {
     if (lds_scene) {
-        if (mode == 0) return launch_one<0, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
-        if (mode == 1) return launch_one<1, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
-        if (mode == 3) return launch_one<3, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
-        if (mode == 4) return launch_one<4, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
-        if (mode == 5) return launch_one<5, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
-        return launch_one<2, true>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
+        if (mode == 0) return launch_one<0, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
+        if (mode == 1) return launch_one<1, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
+        if (mode == 3) return launch_one<3, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
+        if (mode == 4) return launch_one<4, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
+        if (mode == 5) return launch_one<5, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
+        return launch_one<2, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
     }
-    if (mode == 0) return launch_one<0, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
-    if (mode == 1) return launch_one<1, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
-    if (mode == 3) return launch_one<3, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
-    if (mode == 4) return launch_one<4, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
-    if (mode == 5) return launch_one<5, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
-    return launch_one<2, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, num_cus, stream, blocks_per_cu);
+    if (mode == 0) return launch_one<0, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
+    if (mode == 1) return launch_one<1, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
+    if (mode == 3) return launch_one<3, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
+    if (mode == 4) return launch_one<4, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
+    if (mode == 5) return launch_one<5, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
+    return launch_one<2, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
 }
 
 }  // namespace
@@ -726,11 +751,9 @@ hipError_t launch_wave_queue(const SceneView &sc, const FrameParams &fp, int bvh
     // fixes it at 64, which is also the reference's limit)
     if (bvh_depth > 64) return hipErrorInvalidValue;
     const int stack = std::max(bvh_depth, 1);
-    const size_t stack_bytes = (size_t)stack * kThreads * sizeof(StackEntry);
     const size_t scene_bytes = wave_queue_scene_lds_bytes(sc);
     static const size_t lds_scene_budget = std::getenv("DRT_LDS_SCENE_KB") ? (size_t)std::atoi(std::getenv("DRT_LDS_SCENE_KB")) * 1024 : kLdsSceneBytes;
     const bool lds_scene = scene_bytes <= lds_scene_budget;
-    const size_t lds_bytes = stack_bytes + (lds_scene ? scene_bytes : 0);
     hipError_t e = hipMemsetAsync(chunk_counter, 0, sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
     static const char *names[2][6] = { { "wave_queue<lean,hbm-scene>", "wave_queue<general,hbm-scene>", "wave_queue<counting,hbm-scene>", "wave_queue<lean+alpha,hbm-scene>",
@@ -739,10 +762,8 @@ hipError_t launch_wave_queue(const SceneView &sc, const FrameParams &fp, int bvh
                                          "wave_queue<lean+sun,lds-scene>", "wave_queue<lean+alpha+sun,lds-scene>" } };
     if (kernel_name) *kernel_name = names[lds_scene ? 1 : 0][mode];
     float4 *s4 = static_cast<float4 *>(samples);
-    int blocks_per_cu = 0;
-    e = launch_mode(sc, fp, mode, lds_scene, chunk_counter, s4, (uint32_t)stack, lds_bytes, num_cus, stream, &blocks_per_cu);
+    e = launch_mode(sc, fp, mode, lds_scene, chunk_counter, s4, (uint32_t)stack, lds_scene ? scene_bytes : 0, num_cus, stream, launch_shape);
     if (e != hipSuccess) return e;
-    if (launch_shape) { launch_shape[0] = stack; launch_shape[1] = blocks_per_cu; launch_shape[2] = (int)(lds_bytes / 1024); }
     const uint32_t local_pixels = fp.width * fp.local_rows;
     hipLaunchKernelGGL(resolve_kernel, dim3((local_pixels + 255) / 256), dim3(256), 0, stream, s4, fp.accum,
                        reinterpret_cast<float4 *>(fp.rgba), local_pixels, fp.n_frames, fp.frame_first + fp.n_frames - 1);

@@ -18,7 +18,7 @@ constexpr size_t kLdsSceneBytes = 40 * 1024;     // stage the traversal data in 
 size_t wave_queue_sample_bytes(const FrameParams &frame);
 hipError_t launch_wave_queue(const SceneView &scene, const FrameParams &frame, int bvh_depth, int mode, bool scene_has_alpha,
                              unsigned int *chunk_counter, void *samples, int num_cus, hipStream_t stream, const char **kernel_name,
-                             int *launch_shape /* out, may be null: stack slots per lane, workgroups per CU, LDS KiB per workgroup */);
+                             int *launch_shape /* out[4], may be null: stack slots per lane, workgroups per CU, LDS KiB per workgroup, threads per workgroup */);
 
 // debug: d_out2[0] += #floats in [first_bits, first_bits+count) where exact_rcp != 1.0f/x (which 0) or exact_sqrt != sqrtf (which 1),
 // d_out2[1] += #floats on the fast path
