@@ -92,7 +92,7 @@ DRT_DEV int lane_rank(unsigned long long mask) {        // set bits below this l
 #else
 #define DRT_OCCUPANCY_ATTR
 #endif
-template <int MODE, bool LDS_SCENE>
+template <int MODE, bool LDS_SCENE, bool REF16>
 __global__ __launch_bounds__(kBigThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel(const SceneView sc, const FrameParams fp,
                                                               unsigned int *chunk_counter, uint32_t n_chunks, uint32_t tiles_x,
                                                               float4 *samples, uint32_t stack_entries) {
@@ -104,15 +104,31 @@ __global__ __launch_bounds__(kBigThreads) DRT_OCCUPANCY_ATTR void wave_queue_ker
     extern __shared__ uint4 lds_raw[];
     const int tid = threadIdx.x;
     const uint32_t wg = blockDim.x;                                          // 256 or 512 (launch_one)
-    StackEntry *const stack_base = reinterpret_cast<StackEntry *>(lds_raw) + tid;
-#define STACK(level) stack_base[__umul24((uint32_t)(level), wg)]                // entry [level][tid]
+    // Traversal stack, entry [level][tid]: 8 bytes (node reference + entry distance), or -- when that is what limits the waves
+    // per CU and every reference fits 15 bits + the leaf bit -- 4 + 2 bytes in two arrays (REF16, chosen by launch_one)
+    // (addresses are formed from the scalar bases at every access: no per-lane pointer lives across the kernel)
+    StackEntry *const stack_base = reinterpret_cast<StackEntry *>(lds_raw);
+    float *const stack_dist = reinterpret_cast<float *>(lds_raw);
+    unsigned short *const stack_ref = reinterpret_cast<unsigned short *>(reinterpret_cast<float *>(lds_raw) + stack_entries * wg);
+    auto stack_store = [&](int level, StackEntry e) {
+        const uint32_t at = __umul24((uint32_t)level, wg) + (uint32_t)tid;
+        if (REF16) { stack_dist[at] = e.dist; stack_ref[at] = (unsigned short)((e.ref & 0x7fffu) | ((e.ref >> 16) & 0x8000u)); }
+        else stack_base[at] = e;
+    };
+    auto stack_load = [&](int level) {
+        const uint32_t at = __umul24((uint32_t)level, wg) + (uint32_t)tid;
+        StackEntry e;
+        if (REF16) { const uint32_t r = stack_ref[at]; e.ref = (r & 0x7fffu) | ((r & 0x8000u) << 16); e.dist = stack_dist[at]; }
+        else e = stack_base[at];
+        return e;
+    };
     const int lane = tid & 63;
     // The kernel's own execution span (first wave in to last wave out, constant-rate clock): what a profiler reports as
     // the kernel's duration, also when launches from several streams share the GPU and stream events include queueing.
     if (fp.span && lane == 0) atomicMax(&fp.span[0], ~(unsigned long long)wall_clock64());
 
     // ---- scene source: LDS copy (indexed in uint4 units from lds_raw) or HBM ----
-    const uint32_t kSceneBase = stack_entries * (wg * (uint32_t)sizeof(StackEntry) / 16u);
+    const uint32_t kSceneBase = stack_entries * (wg * (REF16 ? 6u : (uint32_t)sizeof(StackEntry)) / 16u);
     const uint32_t hot_base = kSceneBase + sc.n_inner * 4u;
     const uint32_t leaf_base = hot_base + sc.n_tris * 3u;
     if (LDS_SCENE) {
@@ -231,7 +247,7 @@ __global__ __launch_bounds__(kBigThreads) DRT_OCCUPANCY_ATTR void wave_queue_ker
             // Lean: the pop-time test of BVHTraversal.cuh:38 (-1 < dist < FLT_MAX) can only ever fail for the root -- every
             // other entry was pushed with 0 <= dist < closest -- so it is applied here, once per ray instead of once per pop.
             if (GENERAL || (-1.0f < e.dist && e.dist < FLT_MAX)) {
-                STACK(0) = e;
+                stack_store(0, e);
                 sp = 1;
             }
         }
@@ -300,7 +316,7 @@ __global__ __launch_bounds__(kBigThreads) DRT_OCCUPANCY_ATTR void wave_queue_ker
                         shadow = true; occluded = false; cur = end = 0; sp = 0;
                         if (sc.root_ref != kNoNode && !(slab_intersect(root_min, root_max, ray) < 0)) {   // BVHTraversal.cuh:95-103
                             StackEntry e; e.ref = sc.root_ref; e.dist = 0;
-                            STACK(0) = e;
+                            stack_store(0, e);
                             sp = 1;
                         }
                     }
@@ -460,7 +476,7 @@ __global__ __launch_bounds__(kBigThreads) DRT_OCCUPANCY_ATTR void wave_queue_ker
 
             if (!(cur < end) && sp > 0) {
                 --sp;
-                const StackEntry e = STACK(sp);
+                const StackEntry e = stack_load(sp);
                 bool visit = true;
                 if (!GENERAL) {
                     // :41 (without a hit, hit_t = FLT_MAX > dist); :38 was applied to the root; a shadow traversal has no cull
@@ -483,14 +499,14 @@ __global__ __launch_bounds__(kBigThreads) DRT_OCCUPANCY_ATTR void wave_queue_ker
                         ea.ref = first_is_1 ? c.ref1 : c.ref2; ea.dist = first_is_1 ? d1 : d2;
                         eb.ref = first_is_1 ? c.ref2 : c.ref1; eb.dist = first_is_1 ? d2 : d1;
                         const float limit = SUN && shadow ? FLT_MAX : hit_t;        // RayTest pushes every box it hits (:122-129)
-                        if (ea.dist < limit) { STACK(sp) = ea; ++sp; }
+                        if (ea.dist < limit) { stack_store(sp, ea); ++sp; }
                         if (eb.dist < limit) {
                             // A near child that is a leaf goes straight to T: pushed, it would be this lane's next pop, and it would
                             // pass :41 because nothing changes hit_t in between (0 to -5 % on the benchmark scenes)
                             if (eb.ref & kLeafBit) {
                                 const LeafRange leaf = fetch_leaf(eb.ref & ~kLeafBit);
                                 cur = leaf.start; end = leaf.start + leaf.count;
-                            } else { STACK(sp) = eb; ++sp; }
+                            } else { stack_store(sp, eb); ++sp; }
                         }
                     } else {
                         const ChildPair c = fetch_children(e.ref);
@@ -504,8 +520,8 @@ __global__ __launch_bounds__(kBigThreads) DRT_OCCUPANCY_ATTR void wave_queue_ker
                         StackEntry e2; e2.ref = c.ref2; e2.dist = d2;
                         const StackEntry ea = first_is_1 ? e1 : e2, eb = first_is_1 ? e2 : e1;
                         const bool pa = first_is_1 ? push1 : push2, pb = first_is_1 ? push2 : push1;
-                        if (pa) { STACK(sp) = ea; ++sp; }
-                        if (pb) { STACK(sp) = eb; ++sp; }
+                        if (pa) { stack_store(sp, ea); ++sp; }
+                        if (pb) { stack_store(sp, eb); ++sp; }
                     }
                 }
             }
@@ -547,7 +563,7 @@ __global__ __launch_bounds__(kBigThreads) DRT_OCCUPANCY_ATTR void wave_queue_ker
                     // what the next N step would do for this lane if its top entry is a leaf that survives :41 -- done here, the
                     // lane stays in T.  (A culled leaf or an interior node is left to N.)  Pays on very shallow trees only
                     // (cornell -1.5 %, room +2 %): the host sets fp.leaf_chain by tree depth.
-                    const StackEntry e = STACK(sp - 1);
+                    const StackEntry e = stack_load(sp - 1);
                     if ((e.ref & kLeafBit) && !((SUN && shadow ? FLT_MAX : hit_t) < e.dist)) {
                         --sp;
                         const LeafRange leaf = fetch_leaf(e.ref & ~kLeafBit);
@@ -640,47 +656,28 @@ __global__ __launch_bounds__(256) void hash_cycles_kernel(uint32_t max_len, uint
     }
 }
 
-template <int MODE, bool LDS_SCENE>
-hipError_t launch_one(const SceneView &sc, const FrameParams &fp, unsigned int *chunk_counter, float4 *samples,
-                      uint32_t stack_entries, size_t scene_lds_bytes, int num_cus, hipStream_t stream, int *launch_shape) {
+// Occupancy of one kernel variant at a workgroup size: workgroups per CU (0 = does not fit)
+template <int MODE, bool LDS_SCENE, bool REF16>
+int groups_per_cu(int threads, size_t lds) {
+    auto kernel = wave_queue_kernel<MODE, LDS_SCENE, REF16>;
+    if (lds > 160 * 1024) return 0;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess || n < 1) return 0;
+    return std::min(n, 8 * kThreads / threads);
+}
+
+template <int MODE, bool LDS_SCENE, bool REF16>
+hipError_t launch_config(const SceneView &sc, const FrameParams &fp, unsigned int *chunk_counter, float4 *samples, uint32_t stack_entries,
+                         size_t lds_bytes, int threads, int per_cu, int num_cus, hipStream_t stream) {
     const uint32_t tiles_x = (fp.width + 7) / 8, tiles_y = (fp.local_rows + 7) / 8;
-    auto kernel = wave_queue_kernel<MODE, LDS_SCENE>;
-    // Workgroup size.  Every workgroup stages its own copy of an LDS scene next to its lanes' stacks, so a scene of some size
-    // (room: 17.6 KB) is amortised over twice the waves by a 512-thread group: room 4 -> 6 waves per SIMD.  Whichever size
-    // keeps more waves resident wins; 256 on a tie.  (Waves never synchronise after the staging, the size is only packaging.)
-    static int cached_threads = 0, cached_per_cu = 0;          // one set per instantiation
-    static size_t cached_key = ~(size_t)0;
-    const size_t key = scene_lds_bytes * 131u + stack_entries;
-    if (cached_threads == 0 || cached_key != key) {
-        int best_threads = kThreads, best_per_cu = 1, best_waves = 0;
-        for (int threads : { kThreads, kBigThreads }) {
-            if (threads != kThreads && (!LDS_SCENE || scene_lds_bytes < 4096)) continue;
-            const size_t lds = (size_t)stack_entries * threads * sizeof(StackEntry) + scene_lds_bytes;
-            if (lds > 160 * 1024) continue;
-            if (lds > 64 * 1024 &&
-                hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) continue;
-            int n = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, threads, lds) != hipSuccess || n < 1) n = threads == kThreads ? 1 : 0;
-            n = std::min(n, 8 * kThreads / threads);
-            if (n * threads / 64 > best_waves) { best_waves = n * threads / 64; best_threads = threads; best_per_cu = n; }
-        }
-        if (const char *cap = std::getenv("DRT_MAX_BLOCKS_PER_CU")) best_per_cu = std::max(1, std::min(best_per_cu, std::atoi(cap)));
-        if (const char *force = std::getenv("DRT_WG_THREADS")) {       // A/B: force the small group
-            if (std::atoi(force) == kThreads && best_threads != kThreads) {
-                int n = 1;
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kThreads, (size_t)stack_entries * kThreads * sizeof(StackEntry) + scene_lds_bytes);
-                best_threads = kThreads; best_per_cu = std::max(1, std::min(n, 8));
-            }
-        }
-        cached_threads = best_threads; cached_per_cu = best_per_cu; cached_key = key;
-    }
-    const int threads = cached_threads, per_cu = cached_per_cu, waves_per_wg = threads / 64;
-    const size_t lds_bytes = (size_t)stack_entries * threads * sizeof(StackEntry) + scene_lds_bytes;
+    auto kernel = wave_queue_kernel<MODE, LDS_SCENE, REF16>;
+    const int waves_per_wg = threads / 64;
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    if (launch_shape) { launch_shape[0] = (int)stack_entries; launch_shape[1] = per_cu; launch_shape[2] = (int)(lds_bytes / 1024); launch_shape[3] = threads; }
     // persistent grid: as many workgroups as the chip keeps resident (registers and LDS decide), never more than
     // there are chunks to hand out.  Workgroups are independent, so a mis-estimate only costs speed.
     const uint64_t n_chunks = (uint64_t)tiles_x * tiles_y * fp.n_frames;
@@ -701,6 +698,50 @@ hipError_t launch_one(const SceneView &sc, const FrameParams &fp, unsigned int *
     const int blocks = (int)std::max<uint64_t>(1, want);
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(threads), lds_bytes, stream, sc, fp, chunk_counter, (uint32_t)n_chunks, tiles_x, samples, stack_entries);
     return hipGetLastError();
+}
+
+template <int MODE, bool LDS_SCENE>
+hipError_t launch_one(const SceneView &sc, const FrameParams &fp, unsigned int *chunk_counter, float4 *samples,
+                      uint32_t stack_entries, size_t scene_lds_bytes, int num_cus, hipStream_t stream, int *launch_shape) {
+    // Two packaging choices, both made for the number of waves a CU keeps resident (ties: the plain one).
+    //  * Workgroup size.  Every workgroup stages its own copy of an LDS scene next to its lanes' stacks, so a scene of some
+    //    size (room: 17.6 KB) is amortised over twice the waves by a 512-thread group: room 4 -> 6 waves per SIMD.  (Waves
+    //    never synchronise after the staging.)
+    //  * Stack entry size.  A deep tree read from HBM is limited by its stacks alone (16 levels x 8 B x 256 lanes = 32 KB per
+    //    group: 5 per CU); 6-byte entries (16-bit references, when they fit) make it 6 ...
+    constexpr bool kLean = MODE == 0 || MODE == 3 || MODE == 4 || MODE == 5;
+    static int cached_threads = 0, cached_per_cu = 0, cached_entry_bytes = 8;          // one set per instantiation
+    static size_t cached_key = ~(size_t)0;
+    // ... where traversal is what the launch is made of: with the camera inside the scene's bounds every primary ray walks the
+    // tree (cs16_dust, a closed map: -10 %).  Seen from outside with sky around it (dense_monkey: 1.2 rays per sample) the
+    // extra waves gain nothing and the second LDS operation per stack access costs 5 %.
+    bool camera_inside = true;
+    for (int k = 0; k < 3; k++) camera_inside = camera_inside && fp.cam_pos[k] >= sc.root_min[k] && fp.cam_pos[k] <= sc.root_max[k];
+    const bool refs_fit_16 = kLean && !LDS_SCENE && camera_inside && sc.n_inner < 0x8000u && sc.n_leaves < 0x8000u;
+    const size_t key = (scene_lds_bytes * 131u + stack_entries) * 2u + (refs_fit_16 ? 1u : 0u);
+    if (cached_threads == 0 || cached_key != key) {
+        static const bool only_small = std::getenv("DRT_WG_THREADS") && std::atoi(std::getenv("DRT_WG_THREADS")) == kThreads;      // A/B switches
+        static const bool only_wide = std::getenv("DRT_STACK_REF16") && std::atoi(std::getenv("DRT_STACK_REF16")) == 0;
+        int best_threads = kThreads, best_entry = 8;
+        int best_per_cu = std::max(1, groups_per_cu<MODE, LDS_SCENE, false>(kThreads, (size_t)stack_entries * kThreads * 8 + scene_lds_bytes));
+        int best_waves = best_per_cu * kThreads / 64;
+        if (LDS_SCENE && scene_lds_bytes >= 4096 && !only_small) {
+            const int n = groups_per_cu<MODE, LDS_SCENE, false>(kBigThreads, (size_t)stack_entries * kBigThreads * 8 + scene_lds_bytes);
+            if (n * kBigThreads / 64 > best_waves) { best_waves = n * kBigThreads / 64; best_threads = kBigThreads; best_per_cu = n; }
+        }
+        if (refs_fit_16 && !only_wide) {
+            const int n = groups_per_cu<MODE, LDS_SCENE, kLean && !LDS_SCENE>(kThreads, (size_t)stack_entries * kThreads * 6 + scene_lds_bytes);
+            if (n * kThreads / 64 > best_waves) { best_waves = n * kThreads / 64; best_threads = kThreads; best_per_cu = n; best_entry = 6; }
+        }
+        if (const char *cap = std::getenv("DRT_MAX_BLOCKS_PER_CU")) best_per_cu = std::max(1, std::min(best_per_cu, std::atoi(cap)));
+        cached_threads = best_threads; cached_per_cu = best_per_cu; cached_entry_bytes = best_entry; cached_key = key;
+    }
+    const int threads = cached_threads, per_cu = cached_per_cu;
+    const size_t lds_bytes = (size_t)stack_entries * threads * cached_entry_bytes + scene_lds_bytes;
+    if (launch_shape) { launch_shape[0] = (int)stack_entries; launch_shape[1] = per_cu; launch_shape[2] = (int)(lds_bytes / 1024); launch_shape[3] = threads + (cached_entry_bytes == 6 ? 1 : 0); }
+    if (cached_entry_bytes == 6)
+        return launch_config<MODE, LDS_SCENE, kLean && !LDS_SCENE>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, threads, per_cu, num_cus, stream);
+    return launch_config<MODE, LDS_SCENE, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, threads, per_cu, num_cus, stream);
 }
 
 hipError_t launch_mode(const SceneView &sc, const FrameParams &fp, int mode, bool lds_scene, unsigned int *chunk_counter,
