@@ -465,7 +465,7 @@ int drt_renderer_kernel_span(const drt_renderer *r, float *ms) {
 int drt_renderer_kernel_info(const drt_renderer *r, char *buf, size_t cap) {
     if (!r || !buf || cap == 0) return fail(DRT_ERR_INVALID, "bad argument");
     if (r->launch_shape[1] > 0 && std::strncmp(r->kernel_name, "wave_queue", 10) == 0)
-        std::snprintf(buf, cap, "%s stack=%d%s wg/CU=%d%s lds=%dKiB", r->kernel_name, r->launch_shape[0], (r->launch_shape[3] & 1) ? "x6B" : "",
+        std::snprintf(buf, cap, "%s stack=%d%s wg/CU=%d%s lds=%dKiB", r->kernel_name, r->launch_shape[0], (r->launch_shape[3] & 1) ? "x6B" : ((r->launch_shape[3] & 2) ? " tris=3" : ""),
                       r->launch_shape[1], r->launch_shape[3] >= 512 ? "x512" : "", r->launch_shape[2]);
     else
         std::snprintf(buf, cap, "%s", r->kernel_name);

@@ -92,7 +92,7 @@ DRT_DEV int lane_rank(unsigned long long mask) {        // set bits below this l
 #else
 #define DRT_OCCUPANCY_ATTR
 #endif
-template <int MODE, bool LDS_SCENE, bool REF16>
+template <int MODE, bool LDS_SCENE, bool REF16, int TRIS>
 __global__ __launch_bounds__(kBigThreads) DRT_OCCUPANCY_ATTR void wave_queue_kernel(const SceneView sc, const FrameParams fp,
                                                               unsigned int *chunk_counter, uint32_t n_chunks, uint32_t tiles_x,
                                                               float4 *samples, uint32_t stack_entries) {
@@ -536,7 +536,36 @@ __global__ __launch_bounds__(kBigThreads) DRT_OCCUPANCY_ATTR void wave_queue_ker
             if (__popcll(~m_t & m_sp) >= vote_node || __popcll(idle & m_dir) >= vote_dir ||
                 __popcll(idle & ~m_dir & ~m_fin) >= vote_shade) break;
             if (COUNT) { d_exec[0]++; d_lanes[0] += (unsigned long long)__popcll(m_t); d_t0 = __builtin_amdgcn_s_memtime(); }
-            if (!GENERAL && kTrianglesPerStep == 2) {
+            constexpr int kTrisWide = TRIS;
+            if (!GENERAL && kTrisWide > 2) {
+                // three triangles of the leaf per step: more loads in flight per memory round trip, for trees read from HBM
+                // (at 94 VGPR = one wave per SIMD less; launch_one decides where that trade pays)
+                if (cur < end) {
+                    const int i0 = cur;
+                    cur = min(i0 + kTrisWide, end);
+                    int idx[kTrisWide];
+                    TriTest tt[kTrisWide];
+#pragma unroll
+                    for (int k = 0; k < kTrisWide; k++) { idx[k] = min(i0 + k, end - 1); tt[k] = fetch_tri(idx[k]); }
+                    float tk[kTrisWide], uk[kTrisWide], vk[kTrisWide];
+                    bool hk[kTrisWide];
+#pragma unroll
+                    for (int k = 0; k < kTrisWide; k++)
+                        hk[k] = tri_intersect_flat(ray, tt[k].v0, tt[k].e1, tt[k].e2, tk[k], uk[k], vk[k]) & (i0 + k < end);
+                    if (SUN && shadow) {
+                        bool occ = false;
+#pragma unroll
+                        for (int k = 0; k < kTrisWide; k++) occ = occ || (hk[k] && (!ALPHA || any_hit(sc, idx[k], mk3(1.0f - uk[k] - vk[k], uk[k], vk[k]))));
+                        if (occ) { occluded = true; cur = end = 0; sp = 0; }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < kTrisWide; k++)
+                            if (hk[k] && tk[k] < hit_t && (!ALPHA || any_hit(sc, idx[k], mk3(1.0f - uk[k] - vk[k], uk[k], vk[k])))) {
+                                hit_t = tk[k]; hit_prim = idx[k]; hit_u = uk[k]; hit_v = vk[k];
+                            }
+                    }
+                }
+            } else if (!GENERAL && kTrianglesPerStep == 2) {
                 // lean variant: two consecutive triangles of the leaf per step (both loads in flight together, two
                 // independent dependency chains to interleave); hits are applied in leaf order, so ties resolve as in
                 // the one-at-a-time loop.  A lane with one triangle left tests it twice and ignores the second result.
@@ -657,9 +686,9 @@ __global__ __launch_bounds__(256) void hash_cycles_kernel(uint32_t max_len, uint
 }
 
 // Occupancy of one kernel variant at a workgroup size: workgroups per CU (0 = does not fit)
-template <int MODE, bool LDS_SCENE, bool REF16>
+template <int MODE, bool LDS_SCENE, bool REF16, int TRIS = 2>
 int groups_per_cu(int threads, size_t lds) {
-    auto kernel = wave_queue_kernel<MODE, LDS_SCENE, REF16>;
+    auto kernel = wave_queue_kernel<MODE, LDS_SCENE, REF16, TRIS>;
     if (lds > 160 * 1024) return 0;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return 0;
@@ -668,11 +697,11 @@ int groups_per_cu(int threads, size_t lds) {
     return std::min(n, 8 * kThreads / threads);
 }
 
-template <int MODE, bool LDS_SCENE, bool REF16>
+template <int MODE, bool LDS_SCENE, bool REF16, int TRIS = 2>
 hipError_t launch_config(const SceneView &sc, const FrameParams &fp, unsigned int *chunk_counter, float4 *samples, uint32_t stack_entries,
                          size_t lds_bytes, int threads, int per_cu, int num_cus, hipStream_t stream) {
     const uint32_t tiles_x = (fp.width + 7) / 8, tiles_y = (fp.local_rows + 7) / 8;
-    auto kernel = wave_queue_kernel<MODE, LDS_SCENE, REF16>;
+    auto kernel = wave_queue_kernel<MODE, LDS_SCENE, REF16, TRIS>;
     const int waves_per_wg = threads / 64;
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -736,8 +765,25 @@ hipError_t launch_one(const SceneView &sc, const FrameParams &fp, unsigned int *
         if (const char *cap = std::getenv("DRT_MAX_BLOCKS_PER_CU")) best_per_cu = std::max(1, std::min(best_per_cu, std::atoi(cap)));
         cached_threads = best_threads; cached_per_cu = best_per_cu; cached_entry_bytes = best_entry; cached_key = key;
     }
-    const int threads = cached_threads, per_cu = cached_per_cu;
+    const int threads = cached_threads;
+    int per_cu = cached_per_cu;
     const size_t lds_bytes = (size_t)stack_entries * threads * cached_entry_bytes + scene_lds_bytes;
+    //  * Triangles per T step.  Seen from outside (primary rays that mostly miss or end after a bounce: suzanne, dense_monkey)
+    //    the plain kernel reading its tree from HBM is bound by the round trips of its leaf loops, not by occupancy: three
+    //    triangles per step at one wave less is 11 % / 2 % faster there.  From inside (cs16_dust) the extra wave is worth
+    //    more (+9 % the other way), and the alpha-test kernels lose 2 % (tools/ab_hbm_libs.sh).  DRT_TRIS_WIDE=0 disables.
+    constexpr bool kWideCandidate = MODE == 0 && !LDS_SCENE;
+    static const bool wide_allowed = !(std::getenv("DRT_TRIS_WIDE") && std::atoi(std::getenv("DRT_TRIS_WIDE")) == 0);
+    if (kWideCandidate && wide_allowed && !camera_inside && cached_entry_bytes == 8) {
+        static int wide_per_cu = -1;
+        static size_t wide_key = ~(size_t)0;
+        if (wide_per_cu < 0 || wide_key != key) { wide_per_cu = groups_per_cu<MODE, LDS_SCENE, false, kWideCandidate ? 3 : 2>(threads, lds_bytes); wide_key = key; }
+        if (wide_per_cu > 0) {
+            per_cu = wide_per_cu;
+            if (launch_shape) { launch_shape[0] = (int)stack_entries; launch_shape[1] = per_cu; launch_shape[2] = (int)(lds_bytes / 1024); launch_shape[3] = threads + 2; }
+            return launch_config<MODE, LDS_SCENE, false, kWideCandidate ? 3 : 2>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, threads, per_cu, num_cus, stream);
+        }
+    }
     if (launch_shape) { launch_shape[0] = (int)stack_entries; launch_shape[1] = per_cu; launch_shape[2] = (int)(lds_bytes / 1024); launch_shape[3] = threads + (cached_entry_bytes == 6 ? 1 : 0); }
     if (cached_entry_bytes == 6)
         return launch_config<MODE, LDS_SCENE, kLean && !LDS_SCENE>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, threads, per_cu, num_cus, stream);
