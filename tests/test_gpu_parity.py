@@ -567,3 +567,26 @@ def test_bench_two_rank_rehearsal_assembles_the_single_device_image():
     assert "sharded image == single-device image: True" in r.stderr
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "stripes8x2" and "REHEARSAL" in d["data"]
+
+
+@pytest.mark.gpu
+def test_kernel_packaging_follows_the_scene_and_the_view():
+    """launch_one picks workgroup size, stack entry size and triangles per T step per scene and view (DESIGN.md 4 / 5.1);
+    whatever it picks, the image is the oracle's.  The choices themselves are pinned here so that a change shows up."""
+    expect = {"cornell_box": "wave_queue<lean,lds-scene> stack=3 wg/CU=6 ",            # small LDS scene: 256 threads, 6 groups
+              "room": "x512",                                                          # 17.6 KB LDS scene: 512-thread groups
+              "cs16_dust": "stack=16x6B wg/CU=6",                                      # deep tree from HBM, camera inside: 6-byte entries
+              "suzanne_plane": "tris=3"}                                               # tree from HBM, camera outside: three triangles per step
+    r = drt.Renderer(0)
+    W, H = 160, 90
+    r.ResizeBuffer(W, H)
+    for name, marker in expect.items():
+        sc, osc = make_pair(name)
+        cam, ocam = cameras(name)
+        s, o = settings_pair(ray_bounce_limit=3, max_samples=100)
+        r.m_RendererSettings = s
+        r.resetAccumulationBuffer()
+        r.RenderBatch(cam, sc, 2)
+        assert marker in r.kernelInfo(), (name, r.kernelInfo())
+        ref, _, _ = oracle.render(osc, ocam, o, W, H, 1, 2)
+        compare(r.GetRenderTargetImage(), ref, name)
