@@ -9,7 +9,7 @@ A "step" is one full progressive render of the frame: reset the accumulation buf
 of the workload (W x H x spp paths: ray generation, BVH traversal, shading, accumulate, resolve) and,
 for N > 1, gather the rank-local framebuffer stripes on rank 0 over RCCL and assemble the image.
 Inputs (scene, BVH, textures) are resident in HBM before the timed region.  One JSON line on rank 0.
-Steps are independent frames; --frames-in-flight (default 3) of them are enqueued at a time, each on its own
+Steps are independent frames; --frames-in-flight (default 3; 2 for the one-second steps of room 4K) of them are enqueued at a time, each on its own
 renderer + HIP stream, so the end-of-launch drain of one frame and its gather overlap the next frame's
 ramp-up.  Every step still does all of its work inside the timed region (drained before the closing sync).
 
@@ -51,9 +51,10 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--workload", default="cornell_box_1080p_8spp_d8", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--frames-in-flight", type=int, default=3,
+    ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="independent frames (steps) kept in flight, each on its own renderer + HIP stream: the drain of one "
-                         "frame overlaps the ramp-up of the next (1 = strictly one after the other)")
+                         "frame overlaps the ramp-up of the next (1 = strictly one after the other).  Default 3; 2 for the "
+                         "workload whose step is a second long (room 4K / 64 spp: 800 ms with 2 in flight, 896 with 3)")
     ap.add_argument("--emulate-shard", default="", help="R/W: render only rank R's stripes of a W-way split on ONE GPU, no gather "
                     "(what one GPU of a W-GPU run computes; for tuning small-shard behaviour on a 1-GPU box)")
     ap.add_argument("--no-roofline-counters", action="store_true", help="skip the counting launch (roofline = null)")
@@ -111,6 +112,8 @@ def load_traffic(workload):
 
 def main():
     args = parse_args()
+    if args.frames_in_flight <= 0:
+        args.frames_in_flight = 2 if args.workload == "room_4k_64spp_d16" else 3
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
