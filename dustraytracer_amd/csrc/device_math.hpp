@@ -115,6 +115,12 @@ DRT_DEV bool random_unit_sphere_try(uint32_t &seed, f3 &p) {
     p = normalize(mk3(x, y, z));
     return dot(p, p) < 1.0f;
 }
+// randomUnitSphereVec3 (Random.cu:50-58) as a loop over random_unit_sphere_try, with the cycle guard
+DRT_DEV f3 random_unit_sphere_vec3_try(uint32_t &seed) {
+    f3 p;
+    for (int tries = 1;; tries++)
+        if (random_unit_sphere_try(seed, p) || tries >= kMaxTries) return p;
+}
 DRT_DEV f2 random_in_unit_disk(uint32_t &seed) {                                                  // :60-66
     for (int tries = 1;; tries++) {
         f2 p;

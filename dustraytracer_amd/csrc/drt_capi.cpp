@@ -100,12 +100,16 @@ struct drt_renderer {
     int num_cus = 256;
     int frames_in_flight = 1;                 // drt_renderer_set_frames_in_flight
     bool use_pixel_walk = false;              // DRT_KERNEL=pixel_walk selects the first (non-persistent) kernel
+    int use_path_pool = 0;                    // DRT_KERNEL=path_pool / wave_queue: 1 = path_pool where it applies, 0 = never
+    unsigned int *pool_status = nullptr;      // device word: set by an aborted path_pool launch
+    PoolTuning pool_tuning;                   // DRT_POOL_THREADS / _PATHS / _MIN_FILL / _PATIENCE
+    uint32_t pool_t_class[3] = { 0, 0, 0 };   // leaf-size classes of the uploaded scene (path_pool's T queues)
     bool scene_has_alpha = false;
     int vote_node = 12, vote_shade = 44, vote_dir = 4, vote_spec = 8;
     int leaf_chain = -1;                              // DRT_LEAF_CHAIN: -1 = by tree depth (<= 4 levels), 0 / 1 = forced
     int vote_tail_node = 4, vote_tail_shade = 36;    // once the queue is empty (DRT_VOTE_TN / DRT_VOTE_TS): pops stop waiting for company   // wave_queue phase-voting thresholds (DRT_VOTE_N/S/R/P override)
     const char *kernel_name = "";
-    int launch_shape[4] = { 0, 0, 0, 0 };    // wave_queue: stack slots per lane, workgroups per CU, LDS KiB per workgroup, threads per workgroup
+    int launch_shape[5] = { 0, 0, 0, 0, 0 }; // wave_queue: stack slots per lane, workgroups per CU, LDS KiB per workgroup, threads per workgroup; path_pool: + pool paths
     // device copy of the scene last rendered
     const drt_scene *uploaded_scene = nullptr;
     uint64_t uploaded_revision = 0;
@@ -303,6 +307,7 @@ drt_renderer *drt_renderer_create(int32_t device) {
     drt_default_settings(&r->settings);
     const char *which = std::getenv("DRT_KERNEL");
     r->use_pixel_walk = which && std::strcmp(which, "pixel_walk") == 0;
+    r->use_path_pool = which && std::strcmp(which, "path_pool") == 0;
     auto env_int = [](const char *name, int dflt) { const char *v = std::getenv(name); return (v && *v) ? std::atoi(v) : dflt; };
     r->vote_node = std::max(1, env_int("DRT_VOTE_N", r->vote_node));
     r->vote_shade = std::max(1, env_int("DRT_VOTE_S", r->vote_shade));
@@ -312,6 +317,9 @@ drt_renderer *drt_renderer_create(int32_t device) {
     r->vote_tail_shade = std::max(1, env_int("DRT_VOTE_TS", r->vote_tail_shade));
     r->leaf_chain = env_int("DRT_LEAF_CHAIN", r->leaf_chain);
     r->sample_budget = (size_t)std::max(1, env_int("DRT_SAMPLE_MB", 1024)) << 20;
+    r->pool_tuning.threads = env_int("DRT_POOL_THREADS", 0); r->pool_tuning.paths = env_int("DRT_POOL_PATHS", 0);
+    r->pool_tuning.min_fill = env_int("DRT_POOL_MIN_FILL", r->pool_tuning.min_fill);
+    r->pool_tuning.patience = env_int("DRT_POOL_PATIENCE", r->pool_tuning.patience);
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) r->num_cus = cus;
     int khz = 0;
@@ -319,7 +327,9 @@ drt_renderer *drt_renderer_create(int32_t device) {
     if (hipEventCreate(&r->ev_start) != hipSuccess || hipEventCreate(&r->ev_stop) != hipSuccess ||
         hipMalloc((void **)&r->counters, sizeof(drt_counters)) != hipSuccess ||
         hipMalloc((void **)&r->spans, sizeof(unsigned long long) * 2 * drt_renderer::kMaxSpans) != hipSuccess ||
-        hipMalloc((void **)&r->tile_counter, sizeof(unsigned int)) != hipSuccess) {
+        hipMalloc((void **)&r->tile_counter, sizeof(unsigned int)) != hipSuccess ||
+        hipMalloc((void **)&r->pool_status, sizeof(unsigned int)) != hipSuccess ||
+        hipMemset(r->pool_status, 0, sizeof(unsigned int)) != hipSuccess) {
         fail(DRT_ERR_DEVICE, "cannot create HIP events / counter buffer");
         drt_renderer_destroy(r);
         return nullptr;
@@ -336,6 +346,7 @@ void drt_renderer_destroy(drt_renderer *r) {
     if (r->counters) (void)hipFree(r->counters);
     if (r->spans) (void)hipFree(r->spans);
     if (r->tile_counter) (void)hipFree(r->tile_counter);
+    if (r->pool_status) (void)hipFree(r->pool_status);
     if (r->samples) (void)hipFree(r->samples);
     if (r->ev_start) (void)hipEventDestroy(r->ev_start);
     if (r->ev_stop) (void)hipEventDestroy(r->ev_stop);
@@ -464,7 +475,10 @@ int drt_renderer_kernel_span(const drt_renderer *r, float *ms) {
 
 int drt_renderer_kernel_info(const drt_renderer *r, char *buf, size_t cap) {
     if (!r || !buf || cap == 0) return fail(DRT_ERR_INVALID, "bad argument");
-    if (r->launch_shape[1] > 0 && std::strncmp(r->kernel_name, "wave_queue", 10) == 0)
+    if (r->launch_shape[1] > 0 && std::strncmp(r->kernel_name, "path_pool", 9) == 0)
+        std::snprintf(buf, cap, "%s stack=%d wg/CU=%d threads=%d paths=%d lds=%dKiB", r->kernel_name, r->launch_shape[0], r->launch_shape[1],
+                      r->launch_shape[3], r->launch_shape[4], r->launch_shape[2]);
+    else if (r->launch_shape[1] > 0 && std::strncmp(r->kernel_name, "wave_queue", 10) == 0)
         std::snprintf(buf, cap, "%s stack=%d%s wg/CU=%d%s lds=%dKiB", r->kernel_name, r->launch_shape[0], (r->launch_shape[3] & 1) ? "x6B" : ((r->launch_shape[3] & 2) ? " tris=3" : ""),
                       r->launch_shape[1], r->launch_shape[3] >= 512 ? "x512" : "", r->launch_shape[2]);
     else
@@ -494,6 +508,7 @@ static int upload_scene(drt_renderer *r, const drt_scene *scene) {
     std::memcpy(v.root_max, ps.root_max, 12);
     r->bvh_depth = ps.depth;
     r->scene_has_alpha = ps.any_alpha_texture;
+    path_pool_leaf_classes(ps.leaves, r->pool_t_class);
     r->uploaded_scene = scene;
     r->uploaded_revision = scene->host.revision;
     return DRT_OK;
@@ -593,6 +608,11 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
             fp.frame_first = r->frame_index + done;
             fp.n_frames = std::min(frames_per_launch, n_frames - done);
             fp.span = r->spans_used < drt_renderer::kMaxSpans ? r->spans + 2 * r->spans_used++ : nullptr;
+            if (r->use_path_pool && !r->counting &&
+                path_pool_supports(r->view, fp, r->bvh_depth, r->scene_has_alpha, wave_queue_scene_lds_bytes(r->view)))
+                HIP_TRY(launch_path_pool(r->view, fp, r->bvh_depth, r->pool_t_class, r->pool_tuning, r->tile_counter, r->samples, r->pool_status,
+                                         r->num_cus, r->stream, &r->kernel_name, r->launch_shape));
+            else
             HIP_TRY(launch_wave_queue(r->view, fp, r->bvh_depth, r->counting ? 2 : 0, r->scene_has_alpha, r->tile_counter,
                                       r->samples, r->num_cus, r->stream, &r->kernel_name, r->launch_shape));
         }
@@ -634,6 +654,14 @@ int drt_renderer_wait(drt_renderer *r, float *delta_ms) {
         r->span_ms = (float)(ticks / (double)r->wall_clock_khz);
     }
     r->pending = false;
+    if (r->use_path_pool) {
+        unsigned int status = 0;
+        HIP_TRY(hipMemcpy(&status, r->pool_status, sizeof status, hipMemcpyDeviceToHost));
+        if (status != 0) {
+            (void)hipMemset(r->pool_status, 0, sizeof status);
+            return fail(DRT_ERR_DEVICE, "path_pool kernel aborted (status " + std::to_string(status) + "): a queue wait exceeded its bound");
+        }
+    }
     return DRT_OK;
 }
 

@@ -1,0 +1,507 @@
+// kernel_path_pool.hip -- "path_pool": the tracing kernel for scenes whose traversal data lives in LDS, with the
+// PATH STATE parked in LDS too and every phase run for 64 paths that all need exactly that phase.
+//
+// wave_queue (kernel_wave_queue.hip) keeps one path per lane in registers and lets the 64 lanes of a wave vote on the
+// phase to run next; its counters say half of every vector instruction is masked-off lanes (profiles/
+// r01_wave_queue_pmc_sq.txt: lane utilisation 0.51) because at any moment the lanes of a wave want different things.
+// Here a lane owns nothing.  A workgroup (one per CU) keeps a POOL of P paths (P ~ 2-3 x its lanes) in LDS, and every
+// path waits in exactly one queue:
+//     N      pop one entry of its traversal stack; interior node: slab-test both children, push     BVHTraversal.cuh:33-72
+//     T0..T3 test the triangles of the leaf it stands on, two per step (one queue per leaf-size class,
+//            so that the lanes of a batch run the same number of steps)                             BVHTraversal.cuh:46-57
+//     B      shade the closest hit, draw the bounce direction, launch the bounce ray                 RayGen.cuh:90-134
+//     E      finish the path (sky term, tone map, gamma, store the sample), take a new sample,
+//            generate its primary ray                                                               RayGen.cuh:63-108,165-171
+// A wave claims up to 64 path ids of ONE queue (the fullest), loads the part of the state that phase needs (16-byte
+// quads, [quad][path]), runs the phase with every lane busy, stores what changed and pushes each id to the queue of its
+// next phase.  Per-lane order of node visits, triangle tests and RNG draws is the reference's, and the arithmetic is the
+// same device_math.hpp code as wave_queue's, so the image is bit-identical; only who computes what when differs.
+//
+// Queues are rings of 16-bit path ids in LDS, multi-producer / multi-consumer inside the workgroup: a producer reserves a
+// position with an atomic add on the tail and writes the id there; a consumer claims [head, head+n) with one
+// compare-and-swap on the head and reads the ids (an entry still 0xFFFF = reserved but not written yet: re-read).
+// Every wait in this kernel is bounded: a wave that polls too long raises the abort flag, all waves leave, the host
+// reports DRT_ERR_DEVICE (status word) -- a logic error must never hang the GPU.
+// No MFMA (branchy scalar fp32 / u32).  Citations are relative to /root/reference/DustRayTracer/src/.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "device_access.hpp"
+#include "device_math.hpp"
+#include "device_scene.hpp"
+#include "render_kernels.hpp"
+
+namespace drt {
+
+namespace {
+
+constexpr int kNQ = 7;                               // queues: N, T0..T3, B, E
+enum : int { QN = 0, QT0 = 1, QB = 5, QE = 6 };
+constexpr uint32_t kEmptyId = 0xFFFFu;
+constexpr uint32_t kHasSample = 1u << 16;            // quadC.w: bounce index (low 16 bits) | flags
+constexpr int kMaxPoolThreads = 1024;                // up to 16 waves per workgroup = 4 per SIMD (128 VGPRs each)
+
+typedef uint32_t pp_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t pp_u32x2 __attribute__((ext_vector_type(2)));
+#define PP_LDS(T) __attribute__((address_space(3))) T
+#if defined(__HIP_DEVICE_COMPILE__)
+DRT_DEV uint4 ld4(uint32_t off) { const pp_u32x4 v = *(PP_LDS(const pp_u32x4) *)off; return make_uint4(v.x, v.y, v.z, v.w); }
+DRT_DEV uint2 ld2(uint32_t off) { const pp_u32x2 v = *(PP_LDS(const pp_u32x2) *)off; return make_uint2(v.x, v.y); }
+DRT_DEV uint32_t ld1(uint32_t off) { return *(PP_LDS(const uint32_t) *)off; }
+DRT_DEV void st4(uint32_t off, uint4 v) { pp_u32x4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; *(PP_LDS(pp_u32x4) *)off = w; }
+DRT_DEV void st2(uint32_t off, uint2 v) { pp_u32x2 w; w.x = v.x; w.y = v.y; *(PP_LDS(pp_u32x2) *)off = w; }
+DRT_DEV void st1(uint32_t off, uint32_t v) { *(PP_LDS(uint32_t) *)off = v; }
+// control words and ring entries are shared between waves: relaxed atomics (never cached in registers), workgroup scope
+DRT_DEV uint32_t ld1_shared(uint32_t off) { return __hip_atomic_load((PP_LDS(uint32_t) *)off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DRT_DEV void st1_shared(uint32_t off, uint32_t v) { __hip_atomic_store((PP_LDS(uint32_t) *)off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DRT_DEV uint32_t ld_id(uint32_t off) { return __hip_atomic_load((PP_LDS(unsigned short) *)off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DRT_DEV void st_id(uint32_t off, uint32_t v) { __hip_atomic_store((PP_LDS(unsigned short) *)off, (unsigned short)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DRT_DEV uint32_t lds_add(uint32_t off, uint32_t v) { return __hip_atomic_fetch_add((PP_LDS(uint32_t) *)off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DRT_DEV bool lds_cas(uint32_t off, uint32_t expect, uint32_t desired) {
+    return __hip_atomic_compare_exchange_strong((PP_LDS(uint32_t) *)off, &expect, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+DRT_DEV void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+DRT_DEV void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+#else       // host pass: never called, only parsed
+__device__ inline uint4 ld4(uint32_t) { return make_uint4(0, 0, 0, 0); }
+__device__ inline uint2 ld2(uint32_t) { return make_uint2(0, 0); }
+__device__ inline uint32_t ld1(uint32_t) { return 0; }
+__device__ inline void st4(uint32_t, uint4) {}
+__device__ inline void st2(uint32_t, uint2) {}
+__device__ inline void st1(uint32_t, uint32_t) {}
+__device__ inline uint32_t ld1_shared(uint32_t) { return 0; }
+__device__ inline void st1_shared(uint32_t, uint32_t) {}
+__device__ inline uint32_t ld_id(uint32_t) { return 0; }
+__device__ inline void st_id(uint32_t, uint32_t) {}
+__device__ inline uint32_t lds_add(uint32_t, uint32_t) { return 0; }
+__device__ inline bool lds_cas(uint32_t, uint32_t, uint32_t) { return false; }
+__device__ inline void lds_release() {}
+__device__ inline void lds_acquire() {}
+#endif
+DRT_DEV unsigned long long pp_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+DRT_DEV int pp_rank(unsigned long long mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+DRT_DEV float u2f(uint32_t u) { return __uint_as_float(u); }
+DRT_DEV uint32_t f2u(float f) { return __float_as_uint(f); }
+
+// LDS map of a workgroup (byte offsets from the start of its dynamic LDS; host and device compute it the same way)
+struct PoolLayout {
+    uint32_t ctrl, rings, quads, stack, scene, total;      // byte offsets; total = bytes needed
+};
+__host__ __device__ inline PoolLayout pool_layout(uint32_t P, uint32_t ring_cap, uint32_t stack_entries, uint32_t scene_bytes) {
+    PoolLayout l;
+    l.ctrl = 0;                                     // head/tail pairs of the kNQ queues (8 B each), then live, abort, exhausted
+    l.rings = 128;
+    l.quads = l.rings + (uint32_t)kNQ * ring_cap * 2u;
+    l.stack = l.quads + 5u * P * 16u;
+    l.scene = l.stack + stack_entries * P * 8u;
+    l.total = l.scene + scene_bytes;
+    return l;
+}
+constexpr uint32_t kCtrlLive = 64, kCtrlAbort = 68, kCtrlExhausted = 72;
+
+// What the host decides per launch (next to FrameParams)
+struct PoolParams {
+    uint32_t P;                // paths in the pool (multiple of 64)
+    uint32_t ring_cap;         // entries per ring: power of two >= P
+    uint32_t stack_entries;    // BVH depth
+    uint32_t total_samples;    // n_chunks * 64 (sample ids beyond the image edge are skipped)
+    uint32_t n_chunks, tiles_x;
+    uint32_t t_class[3];       // leaf step counts (two triangles per step) up to t_class[i] wait in queue T<i>; larger ones in T3
+    uint32_t min_fill;         // a wave prefers waiting to running a batch thinner than this ...
+    uint32_t patience;         // ... for this many polls
+    unsigned int *status;      // device word: != 0 after an aborted launch
+};
+
+template <bool DUMMY>
+__global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneView sc, const FrameParams fp, const PoolParams pp,
+                                                                    unsigned int *sample_counter, float4 *samples) {
+    extern __shared__ uint4 lds_raw[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t wg = blockDim.x;
+    const uint32_t P = pp.P;
+    const uint32_t ring_mask = pp.ring_cap - 1u;
+    const uint32_t scene_bytes = sc.n_inner * 64u + sc.n_tris * 48u + ((sc.n_leaves * 8u + 15u) & ~15u);
+    const PoolLayout lay = pool_layout(P, pp.ring_cap, pp.stack_entries, scene_bytes);
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds_raw);      // low 32 bits of the flat address = LDS offset
+    const uint32_t ctrl = lds_base + lay.ctrl, rings = lds_base + lay.rings, quads = lds_base + lay.quads, stack = lds_base + lay.stack;
+    const uint32_t lds_inner = lds_base + lay.scene, lds_hot = lds_inner + sc.n_inner * 64u, lds_leaf = lds_hot + sc.n_tris * 48u;
+    const uint32_t qA = quads, qB = quads + P * 16u, qC = quads + 2u * P * 16u, qD = quads + 3u * P * 16u, qE = quads + 4u * P * 16u;
+
+    if (fp.span && lane == 0) atomicMax(&fp.span[0], ~(unsigned long long)wall_clock64());
+
+    // ---- prologue: scene copy, empty rings, every pool slot waits in E without a sample ----
+    {
+        const uint4 *g_inner = reinterpret_cast<const uint4 *>(sc.inner);
+        const uint4 *g_hot = reinterpret_cast<const uint4 *>(sc.tri_hot);
+        for (uint32_t i = tid; i < sc.n_inner * 4u; i += wg) st4(lds_inner + i * 16u, g_inner[i]);
+        for (uint32_t i = tid; i < sc.n_tris * 3u; i += wg) st4(lds_hot + i * 16u, g_hot[i]);
+        for (uint32_t i = tid; i < sc.n_leaves; i += wg) st2(lds_leaf + i * 8u, make_uint2((uint32_t)sc.leaves[i].start, (uint32_t)sc.leaves[i].count));
+        for (uint32_t i = tid; i < (uint32_t)kNQ * pp.ring_cap; i += wg) st_id(rings + i * 2u, kEmptyId);
+        for (uint32_t i = tid; i < 32u; i += wg) st1(ctrl + i * 4u, 0u);
+        for (uint32_t i = tid; i < P; i += wg) st1(qC + i * 16u + 12u, 0u);            // no sample yet
+        __syncthreads();
+        for (uint32_t i = tid; i < P; i += wg) st_id(rings + ((uint32_t)QE * pp.ring_cap + i) * 2u, i);
+        if (tid == 0) { st1(ctrl + QE * 8u + 4u, P); st1(ctrl + kCtrlLive, P); }
+        __syncthreads();
+    }
+
+    auto fetch_tri = [&](int i) -> TriTest {
+        const uint32_t q = lds_hot + __umul24((uint32_t)i, 48u);
+        const uint4 a = ld4(q), b = ld4(q + 16); const uint32_t c = ld1(q + 32);
+        TriTest t;
+        t.v0 = mk3(u2f(a.x), u2f(a.y), u2f(a.z)); t.e1 = mk3(u2f(a.w), u2f(b.x), u2f(b.y)); t.e2 = mk3(u2f(b.z), u2f(b.w), u2f(c));
+        return t;
+    };
+    auto fetch_children = [&](uint32_t index) -> ChildPair {
+        const uint32_t q = lds_inner + index * 64u;
+        const uint4 a = ld4(q), b = ld4(q + 16), c = ld4(q + 32); const uint2 r = ld2(q + 48);
+        ChildPair p;
+        p.min1 = mk3(u2f(a.x), u2f(a.y), u2f(a.z)); p.max1 = mk3(u2f(a.w), u2f(b.x), u2f(b.y));
+        p.min2 = mk3(u2f(b.z), u2f(b.w), u2f(c.x)); p.max2 = mk3(u2f(c.y), u2f(c.z), u2f(c.w));
+        p.ref1 = r.x; p.ref2 = r.y;
+        return p;
+    };
+    auto fetch_face_normal = [&](int prim) -> f3 {
+        const uint32_t q = lds_hot + __umul24((uint32_t)prim, 48u) + 36u;
+        return mk3(u2f(ld1(q)), u2f(ld1(q + 4)), u2f(ld1(q + 8)));
+    };
+    // leaf -> (first triangle, end) packed with the stack height, and the T queue of its size class
+    auto leaf_state = [&](uint32_t leaf_id, int sp, uint32_t &packed) -> int {
+        const uint2 lr = ld2(lds_leaf + leaf_id * 8u);
+        const uint32_t cur = lr.x, end = lr.x + lr.y;
+        packed = cur | (end << 12) | ((uint32_t)sp << 24);
+        const uint32_t steps = (lr.y + 1u) >> 1;
+        return QT0 + (steps <= pp.t_class[0] ? 0 : (steps <= pp.t_class[1] ? 1 : (steps <= pp.t_class[2] ? 2 : 3)));
+    };
+    // traversal over: a path with a hit is shaded (B), one without ends on the sky (E)
+    auto after_traversal = [&](float hit_t) -> int { return hit_t < FLT_MAX ? QB : QE; };
+    auto push = [&](int q, uint32_t id) {
+        const uint32_t pos = lds_add(ctrl + (uint32_t)q * 8u + 4u, 1u);
+        st_id(rings + ((uint32_t)q * pp.ring_cap + (pos & ring_mask)) * 2u, id);
+    };
+    const f3 root_min = ld3(sc.root_min), root_max = ld3(sc.root_max);
+    // TraceRay.cu:15-20 + BVHTraversal.cuh:22-26,38: the root goes on the stack with its slab distance when -1 < d < FLT_MAX
+    auto begin_closest = [&](const Ray &ray, uint32_t id) -> int {
+        if (sc.root_ref == kNoNode) return 0;
+        const float d = slab_intersect(root_min, root_max, ray);
+        if (!(-1.0f < d && d < FLT_MAX)) return 0;
+        st2(stack + id * 8u, make_uint2(sc.root_ref, f2u(d)));
+        return 1;
+    };
+    auto store_new_ray = [&](uint32_t id, const Ray &ray, int sp, uint32_t bounce_flags, uint32_t seed) {
+        st4(qA + id * 16u, make_uint4(f2u(ray.orig.x), f2u(ray.orig.y), f2u(ray.orig.z), f2u(FLT_MAX)));
+        st4(qB + id * 16u, make_uint4(f2u(ray.dir.x), f2u(ray.dir.y), f2u(ray.dir.z), (uint32_t)sp << 24));
+        st4(qC + id * 16u, make_uint4(f2u(ray.inv_dir.x), f2u(ray.inv_dir.y), f2u(ray.inv_dir.z), bounce_flags));
+        st4(qD + id * 16u, make_uint4(0u, 0u, 0xFFFFFFFFu, seed));
+    };
+
+    uint32_t polls = 0, idle_polls = 0;
+    for (;;) {
+        // ---------------- choose a queue: the fullest one; claim up to 64 of its ids ----------------
+        uint32_t my_head = 0, my_tail = 0;
+        if (lane < kNQ) { my_head = ld1_shared(ctrl + (uint32_t)lane * 8u); my_tail = ld1_shared(ctrl + (uint32_t)lane * 8u + 4u); }
+        const int my_avail = (int)(my_tail - my_head);
+        int q = -1, avail = 0;
+#pragma unroll
+        for (int k = 0; k < kNQ; k++) {
+            const int a = __builtin_amdgcn_readlane(my_avail, k);
+            if (a > avail) { avail = a; q = k; }
+        }
+        const bool aborted = ld1_shared(ctrl + kCtrlAbort) != 0;
+        if (aborted) break;
+        if (q < 0) {
+            if (ld1_shared(ctrl + kCtrlLive) == 0) break;                 // every pool slot retired: the launch is done
+            __builtin_amdgcn_s_sleep(8);
+            if (++idle_polls > (1u << 22)) { st1_shared(ctrl + kCtrlAbort, 1u); if (lane == 0 && pp.status) atomicOr(pp.status, 1u); break; }
+            continue;
+        }
+        if ((uint32_t)avail < pp.min_fill && polls < pp.patience && ld1_shared(ctrl + kCtrlExhausted) == 0) {
+            ++polls;
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        const uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)my_head, q);
+        const uint32_t n = (uint32_t)min(avail, 64);
+        int won = 0;
+        if (lane == 0) won = lds_cas(ctrl + (uint32_t)q * 8u, head, head + n) ? 1 : 0;
+        won = __builtin_amdgcn_readfirstlane(won);
+        if (!won) continue;                                               // another wave was faster: look again
+        polls = 0; idle_polls = 0;
+        const bool active = (uint32_t)lane < n;
+        uint32_t id = 0;
+        if (active) {
+            const uint32_t at = rings + ((uint32_t)q * pp.ring_cap + ((head + (uint32_t)lane) & ring_mask)) * 2u;
+            uint32_t spins = 0;
+            for (;;) {
+                id = ld_id(at);
+                if (id != kEmptyId) break;
+                if (++spins > (1u << 24)) { st1_shared(ctrl + kCtrlAbort, 2u); if (pp.status) atomicOr(pp.status, 2u); id = 0; break; }
+            }
+            st_id(at, kEmptyId);
+        }
+        lds_acquire();
+
+        if (q == QN) {
+            // ============ N: pop one stack entry (BVHTraversal.cuh:33-72) ============
+            if (active) {
+                const uint4 A = ld4(qA + id * 16u), C = ld4(qC + id * 16u);
+                int sp = (int)(ld1(qB + id * 16u + 12u) >> 24);
+                const float hit_t = u2f(A.w);
+                Ray ray; ray.orig = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); ray.inv_dir = mk3(u2f(C.x), u2f(C.y), u2f(C.z)); ray.dir = ray.inv_dir;   // (dir is not used by the slab test)
+                --sp;
+                const uint2 e = ld2(stack + ((uint32_t)sp * P + id) * 8u);
+                uint32_t packed = (uint32_t)sp << 24;
+                int dest = -1;
+                // :41 (without a hit, hit_t = FLT_MAX > dist); :38 was applied when the root was pushed
+                if (!(hit_t < u2f(e.y))) {
+                    if (e.x & kLeafBit) dest = leaf_state(e.x & ~kLeafBit, sp, packed);
+                    else {
+                        const ChildPair c = fetch_children(e.x);
+                        const float d1 = slab_entry_or_inf(c.min1, c.max1, ray);
+                        const float d2 = slab_entry_or_inf(c.min2, c.max2, ray);
+                        const bool first_is_1 = d1 > d2;          // farther child first; child 2 first on ties (:63-70)
+                        const uint32_t ra = first_is_1 ? c.ref1 : c.ref2, rb = first_is_1 ? c.ref2 : c.ref1;
+                        const float da = first_is_1 ? d1 : d2, db = first_is_1 ? d2 : d1;
+                        if (da < hit_t) { st2(stack + ((uint32_t)sp * P + id) * 8u, make_uint2(ra, f2u(da))); ++sp; }
+                        packed = (uint32_t)sp << 24;
+                        if (db < hit_t) {
+                            // a near child that is a leaf is this path's next visit and passes :41 (nothing changes hit_t in between)
+                            if (rb & kLeafBit) dest = leaf_state(rb & ~kLeafBit, sp, packed);
+                            else { st2(stack + ((uint32_t)sp * P + id) * 8u, make_uint2(rb, f2u(db))); ++sp; packed = (uint32_t)sp << 24; }
+                        }
+                    }
+                }
+                st1(qB + id * 16u + 12u, packed);
+                if (dest < 0) dest = sp > 0 ? QN : after_traversal(hit_t);
+                lds_release();
+                push(dest, id);
+            }
+        } else if (q >= QT0 && q < QB) {
+            // ============ T: the triangles of one leaf, two per step (Intersection.cu:4-36, BVHTraversal.cuh:46-57) ============
+            Ray ray = make_ray(mk3(0, 0, 0), mk3(0, 0, 1));
+            float hit_t = FLT_MAX, hit_u = 0, hit_v = 0;
+            uint32_t hit_prim = 0xFFFFFFFFu, seed_keep = 0;
+            int cur = 0, end = 0, sp = 0;
+            if (active) {
+                const uint4 A = ld4(qA + id * 16u), B = ld4(qB + id * 16u), D = ld4(qD + id * 16u);
+                ray.orig = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); hit_t = u2f(A.w);
+                ray.dir = mk3(u2f(B.x), u2f(B.y), u2f(B.z));
+                cur = (int)(B.w & 0xFFFu); end = (int)((B.w >> 12) & 0xFFFu); sp = (int)(B.w >> 24);
+                hit_u = u2f(D.x); hit_v = u2f(D.y); hit_prim = D.z; seed_keep = D.w;
+            }
+            const float hit_t_in = hit_t;
+            while (pp_ballot(cur < end) != 0) {
+                if (cur < end) {
+                    const int i = cur;
+                    const bool two = i + 1 < end;
+                    const int j = two ? i + 1 : i;
+                    cur = j + 1;
+                    const TriTest ta = fetch_tri(i), tb = fetch_tri(j);
+                    float t0, u0, v0, t1, u1, v1;
+                    const bool h0 = tri_intersect_flat(ray, ta.v0, ta.e1, ta.e2, t0, u0, v0);
+                    const bool h1 = tri_intersect_flat(ray, tb.v0, tb.e1, tb.e2, t1, u1, v1) & two;
+                    if (h0 && t0 < hit_t) { hit_t = t0; hit_prim = (uint32_t)i; hit_u = u0; hit_v = v0; }
+                    if (h1 && t1 < hit_t) { hit_t = t1; hit_prim = (uint32_t)j; hit_u = u1; hit_v = v1; }
+                }
+            }
+            if (active) {
+                if (hit_t < hit_t_in) {
+                    st1(qA + id * 16u + 12u, f2u(hit_t));
+                    st4(qD + id * 16u, make_uint4(f2u(hit_u), f2u(hit_v), hit_prim, seed_keep));
+                }
+                st1(qB + id * 16u + 12u, (uint32_t)sp << 24);
+                lds_release();
+                push(sp > 0 ? QN : after_traversal(hit_t), id);
+            }
+        } else if (q == QB) {
+            // ============ B: shade the hit, draw the bounce direction, launch the bounce ray (RayGen.cuh:90-134) ============
+            if (active) {
+                const uint4 A = ld4(qA + id * 16u), B = ld4(qB + id * 16u), D = ld4(qD + id * 16u), E = ld4(qE + id * 16u);
+                const uint32_t Cw = ld1(qC + id * 16u + 12u);
+                Ray ray; ray.orig = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); ray.dir = mk3(u2f(B.x), u2f(B.y), u2f(B.z)); ray.inv_dir = ray.dir;
+                const float hit_t = u2f(A.w), hit_u = u2f(D.x), hit_v = u2f(D.y);
+                const int hit_prim = (int)D.z;
+                int bounce = (int)(Cw & 0xFFFFu);
+                uint32_t seed = D.w + (uint32_t)bounce;                                    // :91
+                f3 throughput = mk3(u2f(E.x), u2f(E.y), u2f(E.z));
+                const f3 uvw = mk3(1.0f - hit_u - hit_v, hit_u, hit_v);                    // Intersection.cu:31
+                f3 position, normal;                                                       // ClosestHit.cuh:13-24
+                closest_hit_frame(ray, hit_t, fetch_face_normal(hit_prim), position, normal);
+                const TriCold cold = sc.tri_cold[hit_prim];                                // :111-118
+                const MatDev mat = sc.mats[cold.material];
+                if (mat.tex < 0) throughput = throughput * ld3(mat.albedo);
+                else throughput = throughput * tex_get_pixel(sc, sc.texs[mat.tex], interp_uv(cold, uvw));
+                const f3 origin = position + (normal * 0.001f);                            // :121
+                ++bounce;
+                st4(qE + id * 16u, make_uint4(f2u(throughput.x), f2u(throughput.y), f2u(throughput.z), E.w));
+                int dest = QE;
+                if (bounce <= fp.bounce_limit) {                                           // :88 loop condition
+                    const f3 p = random_unit_sphere_vec3_try(seed);                        // :133 (Random.cu:50-58)
+                    const Ray next = make_ray(origin, normal + p);                         // :134
+                    const int sp = begin_closest(next, id);
+                    store_new_ray(id, next, sp, (uint32_t)bounce | kHasSample, seed);
+                    if (sp > 0) dest = QN;                                                 // else: missed the scene's bounds -> sky (hit_t = FLT_MAX)
+                } else {
+                    st1(qA + id * 16u + 12u, 0u);        // the path ends without reaching the sky: E adds no light (hit_t != FLT_MAX)
+                }
+                lds_release();
+                push(dest, id);
+            }
+        } else {
+            // ============ E: finish the path, store its sample; deal a new sample, primary ray (RayGen.cuh:63-108,165-171) ============
+            uint32_t Cw = 0;
+            if (active) {
+                Cw = ld1(qC + id * 16u + 12u);
+                if (Cw & kHasSample) {
+                    const uint4 B = ld4(qB + id * 16u), E = ld4(qE + id * 16u);
+                    const float hit_t = u2f(ld1(qA + id * 16u + 12u));
+                    f3 light = mk3(0, 0, 0);
+                    if (!(hit_t < FLT_MAX))                                                // miss: :99-108
+                        light = light + sky_model(mk3(u2f(B.x), u2f(B.y), u2f(B.z)), ld3(fp.sky_color)) * mk3(u2f(E.x), u2f(E.y), u2f(E.z)) * fp.sky_intensity;
+                    if (fp.tone_mapping) light = uncharted2_filmic(light, fp.exposure);    // :165-169 (wave-uniform branches)
+                    if (fp.gamma_correction) light = gamma_correction(light);
+                    samples[E.w] = make_float4(light.x, light.y, light.z, 0.0f);
+                }
+            }
+            // one global atomic per batch hands out the sample ids
+            const unsigned long long m = pp_ballot(active);
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(sample_counter, (unsigned int)__popcll(m));
+            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+            if (active) {
+                const uint32_t sid = base + (uint32_t)pp_rank(m);
+                if (sid >= pp.total_samples) {
+                    st1_shared(ctrl + kCtrlExhausted, 1u);
+                    lds_add(ctrl + kCtrlLive, 0xFFFFFFFFu);                                // this pool slot retires
+                } else {
+                    // sample id -> (tile, frame, pixel): chunk = 64 samples = one 8x8 tile of one frame, frame-major, tile rows
+                    // visited with a stride (fp.row_step) -- the work order of wave_queue (DRT_CHUNK_ORDER 4)
+                    const uint32_t my_chunk = sid >> 6, my_k = sid & 63u;
+                    const uint32_t n_tiles_all = pp.n_chunks / fp.n_frames;
+                    const uint32_t f_rel = my_chunk / n_tiles_all, tile = my_chunk - f_rel * n_tiles_all;
+                    uint32_t ty = tile / pp.tiles_x;
+                    const uint32_t tx = tile - ty * pp.tiles_x;
+                    ty = (ty * fp.row_step) % (n_tiles_all / pp.tiles_x);
+                    const uint32_t x = tx * 8u + (my_k & 7u), ly = ty * 8u + (my_k >> 3);
+                    int dest = QE;
+                    if (x < fp.width && ly < fp.local_rows) {
+                        const uint32_t y = ((ly / fp.stripe_rows) * fp.world + fp.rank) * fp.stripe_rows + (ly % fp.stripe_rows);
+                        const uint32_t slot = f_rel * (fp.width * fp.local_rows) + ly * fp.width + x;
+                        f2 screen_uv;
+                        screen_uv.x = ((float)x / (float)fp.width) * 2 - 1;
+                        screen_uv.y = ((float)y / (float)fp.height) * 2 - 1;
+                        uint32_t seed = x + y * fp.width;
+                        seed *= fp.frame_first + f_rel;
+                        const Ray ray = camera_get_ray(fp, screen_uv, seed);
+                        int sp = 0;
+                        if (fp.bounce_limit >= 0) sp = begin_closest(ray, id);
+                        store_new_ray(id, ray, sp, kHasSample, seed);
+                        st4(qE + id * 16u, make_uint4(f2u(1.0f), f2u(1.0f), f2u(1.0f), slot));
+                        if (fp.bounce_limit < 0) st1(qA + id * 16u + 12u, 0u);            // RayGen.cuh:88: the loop body never runs, the sample is black
+                        if (sp > 0) dest = QN;
+                    } else {
+                        st1(qC + id * 16u + 12u, 0u);       // a sample id outside the image (partial tile): the slot asks again
+                    }
+                    lds_release();
+                    push(dest, id);
+                }
+            }
+        }
+    }
+
+    if (fp.span && lane == 0) atomicMax(&fp.span[1], (unsigned long long)wall_clock64());
+}
+
+}  // namespace
+
+// Leaf step counts (two triangles per step) -> upper bounds of the first three T queues, chosen so that the steps a
+// batch wastes on shorter leaves (every lane runs as long as the batch's longest leaf) are fewest, each leaf weighted by
+// its size.  At most a dozen distinct values: exhaustive.
+void path_pool_leaf_classes(const std::vector<LeafRange> &leaves, uint32_t out[3]) {
+    std::vector<uint32_t> steps;
+    for (const LeafRange &l : leaves) steps.push_back(((uint32_t)l.count + 1u) / 2u);
+    std::vector<uint32_t> distinct = steps;
+    std::sort(distinct.begin(), distinct.end());
+    distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+    out[0] = out[1] = out[2] = distinct.empty() ? 0u : distinct.back();
+    if (distinct.size() <= 1) return;
+    const size_t m = distinct.size();
+    auto waste = [&](uint32_t b0, uint32_t b1, uint32_t b2) {
+        unsigned long long w = 0;
+        for (uint32_t s : steps) {
+            const uint32_t top = s <= b0 ? b0 : (s <= b1 ? b1 : (s <= b2 ? b2 : distinct.back()));
+            w += (unsigned long long)(top - s) * s;
+        }
+        return w;
+    };
+    unsigned long long best = ~0ull;
+    for (size_t a = 0; a < m; a++)
+        for (size_t b = a; b < m; b++)
+            for (size_t c = b; c < m; c++) {
+                const unsigned long long w = waste(distinct[a], distinct[b], distinct[c]);
+                if (w < best) { best = w; out[0] = distinct[a]; out[1] = distinct[b]; out[2] = distinct[c]; }
+            }
+}
+
+bool path_pool_supports(const SceneView &sc, const FrameParams &fp, int bvh_depth, bool scene_has_alpha, size_t scene_lds_bytes) {
+    if (fp.render_mode != 0 || fp.enable_sunlight || scene_has_alpha) return false;       // lean paths only (so far)
+    if (scene_lds_bytes > kLdsSceneBytes || sc.n_tris >= 4096u || bvh_depth > 200) return false;
+    if (sc.root_ref == kNoNode) return false;
+    return true;
+}
+
+hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_depth, const uint32_t t_class[3], const PoolTuning &tune,
+                            unsigned int *sample_counter, void *samples, unsigned int *status, int num_cus, hipStream_t stream,
+                            const char **kernel_name, int *launch_shape) {
+    if (fp.width == 0 || fp.local_rows == 0 || fp.n_frames == 0) return hipSuccess;
+    const int env_threads = tune.threads, env_paths = tune.paths, env_fill = tune.min_fill, env_patience = tune.patience;
+    const uint32_t tiles_x = (fp.width + 7) / 8, tiles_y = (fp.local_rows + 7) / 8;
+    const uint64_t n_chunks = (uint64_t)tiles_x * tiles_y * fp.n_frames;
+    if (n_chunks * 64ull > 0xFFF00000ull) return hipErrorInvalidValue;
+    const uint32_t stack_entries = (uint32_t)std::max(bvh_depth, 1);
+    const uint32_t scene_bytes = sc.n_inner * 64u + sc.n_tris * 48u + ((sc.n_leaves * 8u + 15u) & ~15u);
+    int threads = env_threads > 0 ? std::min(env_threads, kMaxPoolThreads) / 64 * 64 : 512;
+    threads = std::max(threads, 64);
+    // the pool: as many paths as the CU's LDS holds next to the scene copy, at most 1024, at least twice the lanes
+    uint32_t P = env_paths > 0 ? (uint32_t)env_paths / 64u * 64u : 1024u;
+    P = std::max<uint32_t>(64u, std::min<uint32_t>(P, 4032u));
+    uint32_t ring_cap = 64;
+    for (;;) {
+        ring_cap = 64;
+        while (ring_cap < P) ring_cap *= 2;
+        if (pool_layout(P, ring_cap, stack_entries, scene_bytes).total <= 160u * 1024u || P <= 64u) break;
+        P -= 64u;
+    }
+    const PoolLayout lay = pool_layout(P, ring_cap, stack_entries, scene_bytes);
+    if (lay.total > 160u * 1024u) return hipErrorInvalidValue;
+    auto kernel = path_pool_kernel<true>;
+    if (lay.total > 64u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total);
+        if (e != hipSuccess) return e;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lay.total) != hipSuccess || per_cu < 1) per_cu = 1;
+    PoolParams pp;
+    pp.P = P; pp.ring_cap = ring_cap; pp.stack_entries = stack_entries;
+    pp.total_samples = (uint32_t)(n_chunks * 64ull); pp.n_chunks = (uint32_t)n_chunks; pp.tiles_x = tiles_x;
+    pp.t_class[0] = t_class[0]; pp.t_class[1] = t_class[1]; pp.t_class[2] = t_class[2];
+    pp.min_fill = (uint32_t)std::max(1, std::min(env_fill, 64)); pp.patience = (uint32_t)std::max(0, env_patience);
+    pp.status = status;
+    // one pool fills with P samples at once: never more workgroups than that leaves work for
+    const uint64_t want = std::min<uint64_t>((uint64_t)num_cus * per_cu, std::max<uint64_t>(1, (n_chunks * 64ull + P - 1) / P));
+    hipError_t e = hipMemsetAsync(sample_counter, 0, sizeof(unsigned int), stream);
+    if (e != hipSuccess) return e;
+    if (kernel_name) *kernel_name = "path_pool<lean,lds-scene>";
+    if (launch_shape) { launch_shape[0] = (int)stack_entries; launch_shape[1] = per_cu; launch_shape[2] = (int)(lay.total / 1024); launch_shape[3] = threads; launch_shape[4] = (int)P; }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)want), dim3(threads), lay.total, stream, sc, fp, pp, sample_counter, static_cast<float4 *>(samples));
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_resolve(fp, samples, stream);
+}
+
+}  // namespace drt

@@ -820,6 +820,14 @@ hipError_t launch_hash_cycles(uint32_t max_len, uint32_t *d_out, uint32_t cap_pa
     return hipGetLastError();
 }
 
+// ordered accumulate + resolve of the samples of one launch (RenderKernel.cu:29-34), shared by the tracing kernels
+hipError_t launch_resolve(const FrameParams &fp, void *samples, hipStream_t stream) {
+    const uint32_t local_pixels = fp.width * fp.local_rows;
+    hipLaunchKernelGGL(resolve_kernel, dim3((local_pixels + 255) / 256), dim3(256), 0, stream, static_cast<const float4 *>(samples), fp.accum,
+                       reinterpret_cast<float4 *>(fp.rgba), local_pixels, fp.n_frames, fp.frame_first + fp.n_frames - 1);
+    return hipGetLastError();
+}
+
 size_t wave_queue_scene_lds_bytes(const SceneView &sc) {
     return (size_t)sc.n_inner * sizeof(InnerNode) + (size_t)sc.n_tris * sizeof(TriHot) + (((size_t)sc.n_leaves * sizeof(LeafRange) + 15) & ~(size_t)15);
 }
@@ -851,10 +859,7 @@ hipError_t launch_wave_queue(const SceneView &sc, const FrameParams &fp, int bvh
     float4 *s4 = static_cast<float4 *>(samples);
     e = launch_mode(sc, fp, mode, lds_scene, chunk_counter, s4, (uint32_t)stack, lds_scene ? scene_bytes : 0, num_cus, stream, launch_shape);
     if (e != hipSuccess) return e;
-    const uint32_t local_pixels = fp.width * fp.local_rows;
-    hipLaunchKernelGGL(resolve_kernel, dim3((local_pixels + 255) / 256), dim3(256), 0, stream, s4, fp.accum,
-                       reinterpret_cast<float4 *>(fp.rgba), local_pixels, fp.n_frames, fp.frame_first + fp.n_frames - 1);
-    return hipGetLastError();
+    return launch_resolve(fp, samples, stream);
 }
 
 }  // namespace drt

@@ -20,6 +20,18 @@ hipError_t launch_wave_queue(const SceneView &scene, const FrameParams &frame, i
                              unsigned int *chunk_counter, void *samples, int num_cus, hipStream_t stream, const char **kernel_name,
                              int *launch_shape /* out[4], may be null: stack slots per lane, workgroups per CU, LDS KiB per workgroup, threads per workgroup */);
 
+hipError_t launch_resolve(const FrameParams &frame, void *samples, hipStream_t stream);
+size_t wave_queue_scene_lds_bytes(const SceneView &scene);
+
+// path_pool (kernel_path_pool.hip): path state parked in LDS, phase-homogeneous batches of 64 paths; lean paths of scenes
+// whose traversal data fits LDS.  `status` is a device word the kernel sets when it had to abort (never hangs).
+bool path_pool_supports(const SceneView &scene, const FrameParams &frame, int bvh_depth, bool scene_has_alpha, size_t scene_lds_bytes);
+void path_pool_leaf_classes(const std::vector<LeafRange> &leaves, uint32_t out[3]);
+struct PoolTuning { int threads = 0, paths = 0, min_fill = 48, patience = 8; };      // 0 = the launcher's default
+hipError_t launch_path_pool(const SceneView &scene, const FrameParams &frame, int bvh_depth, const uint32_t t_class[3], const PoolTuning &tune,
+                            unsigned int *sample_counter, void *samples, unsigned int *status, int num_cus, hipStream_t stream, const char **kernel_name,
+                            int *launch_shape /* out[5]: stack slots, workgroups per CU, LDS KiB, threads, pool paths */);
+
 // debug: d_out2[0] += #floats in [first_bits, first_bits+count) where exact_rcp != 1.0f/x (which 0) or exact_sqrt != sqrtf (which 1),
 // d_out2[1] += #floats on the fast path
 hipError_t launch_check_rcp(int which, uint32_t first_bits, unsigned long long count, unsigned long long *d_out2, hipStream_t stream);
