@@ -224,6 +224,7 @@ _sig("drt_shard_rows", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint3
 _sig("drt_debug_decode_image", C.c_int, _P, C.c_size_t, _P, _P, C.c_size_t)
 _sig("drt_debug_kat", C.c_int, C.c_int32, C.c_int32, _P, C.c_size_t, _P, C.c_size_t, C.c_uint32, C.POINTER(_CameraPOD), C.c_uint32, C.c_uint32)
 _sig("drt_debug_hash_cycles", C.c_int, C.c_int32, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32))
+_sig("drt_debug_pool_stats", C.c_int, _P, _P, C.c_int32)
 _sig("drt_debug_check_rcp", C.c_int, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 _sig("drt_debug_check_sqrt", C.c_int, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 
@@ -440,6 +441,17 @@ class Renderer:
         """Hint that n launches are kept in flight on this device (other renderers on other streams): small launches get
         smaller grids so that they overlap.  Does not change results."""
         _check(_lib.drt_renderer_set_frames_in_flight(self._h, int(n)))
+
+    def poolStats(self, reset=True):
+        """path_pool statistics (renderer created with DRT_POOL_STATS=1): dict queue -> (batches, mean paths per batch, ticks)."""
+        a = np.zeros(32, np.uint64)
+        _check(_lib.drt_debug_pool_stats(self._h, a.ctypes.data, 1 if reset else 0))
+        out = {}
+        for k, name in enumerate(("N", "T0", "T1", "T2", "T3", "B", "E")):
+            b, l, t = int(a[3 * k]), int(a[3 * k + 1]), int(a[3 * k + 2])
+            out[name] = (b, l / max(b, 1), t)
+        out["claim_ticks"], out["idle_polls"], out["lost_claims"], out["wave_ticks"] = int(a[21]), int(a[22]), int(a[23]), int(a[24])
+        return out
 
     def kernelSpanMs(self):
         """Device-measured execution time of the tracing kernel(s) of the last completed batch (no queueing time)."""

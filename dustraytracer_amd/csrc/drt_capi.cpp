@@ -102,6 +102,7 @@ struct drt_renderer {
     bool use_pixel_walk = false;              // DRT_KERNEL=pixel_walk selects the first (non-persistent) kernel
     int use_path_pool = 0;                    // DRT_KERNEL=path_pool / wave_queue: 1 = path_pool where it applies, 0 = never
     unsigned int *pool_status = nullptr;      // device word: set by an aborted path_pool launch
+    PoolScratch pool_scratch;
     PoolTuning pool_tuning;                   // DRT_POOL_THREADS / _PATHS / _MIN_FILL / _PATIENCE
     uint32_t pool_t_class[3] = { 0, 0, 0 };   // leaf-size classes of the uploaded scene (path_pool's T queues)
     bool scene_has_alpha = false;
@@ -320,6 +321,10 @@ drt_renderer *drt_renderer_create(int32_t device) {
     r->pool_tuning.threads = env_int("DRT_POOL_THREADS", 0); r->pool_tuning.paths = env_int("DRT_POOL_PATHS", 0);
     r->pool_tuning.min_fill = env_int("DRT_POOL_MIN_FILL", r->pool_tuning.min_fill);
     r->pool_tuning.patience = env_int("DRT_POOL_PATIENCE", r->pool_tuning.patience);
+    r->pool_tuning.n_loop = env_int("DRT_POOL_N_LOOP", r->pool_tuning.n_loop);
+    r->pool_tuning.n_min_lanes = env_int("DRT_POOL_N_MIN", r->pool_tuning.n_min_lanes);
+    if (env_int("DRT_POOL_STATS", 0) != 0 && hipMalloc((void **)&r->pool_tuning.stats, 32 * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemset(r->pool_tuning.stats, 0, 32 * sizeof(unsigned long long));
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) r->num_cus = cus;
     int khz = 0;
@@ -347,6 +352,9 @@ void drt_renderer_destroy(drt_renderer *r) {
     if (r->spans) (void)hipFree(r->spans);
     if (r->tile_counter) (void)hipFree(r->tile_counter);
     if (r->pool_status) (void)hipFree(r->pool_status);
+    if (r->pool_tuning.stats) (void)hipFree(r->pool_tuning.stats);
+    if (r->pool_scratch.aux) (void)hipFree(r->pool_scratch.aux);
+    if (r->pool_scratch.aux_slot) (void)hipFree(r->pool_scratch.aux_slot);
     if (r->samples) (void)hipFree(r->samples);
     if (r->ev_start) (void)hipEventDestroy(r->ev_start);
     if (r->ev_stop) (void)hipEventDestroy(r->ev_stop);
@@ -610,7 +618,7 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
             fp.span = r->spans_used < drt_renderer::kMaxSpans ? r->spans + 2 * r->spans_used++ : nullptr;
             if (r->use_path_pool && !r->counting &&
                 path_pool_supports(r->view, fp, r->bvh_depth, r->scene_has_alpha, wave_queue_scene_lds_bytes(r->view)))
-                HIP_TRY(launch_path_pool(r->view, fp, r->bvh_depth, r->pool_t_class, r->pool_tuning, r->tile_counter, r->samples, r->pool_status,
+                HIP_TRY(launch_path_pool(r->view, fp, r->bvh_depth, r->pool_t_class, r->pool_tuning, r->pool_scratch, r->tile_counter, r->samples, r->pool_status,
                                          r->num_cus, r->stream, &r->kernel_name, r->launch_shape));
             else
             HIP_TRY(launch_wave_queue(r->view, fp, r->bvh_depth, r->counting ? 2 : 0, r->scene_has_alpha, r->tile_counter,
@@ -748,6 +756,16 @@ int drt_debug_kat(int32_t device, int32_t which, const void *in, size_t in_bytes
     (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
     if (e != hipSuccess) return fail(DRT_ERR_DEVICE, hipGetErrorString(e));
+    return DRT_OK;
+}
+
+int drt_debug_pool_stats(drt_renderer *r, uint64_t out[32], int32_t reset) {
+    if (!r || !out) return fail(DRT_ERR_INVALID, "null argument");
+    if (!r->pool_tuning.stats) return fail(DRT_ERR_INVALID, "renderer was not created with DRT_POOL_STATS=1");
+    HIP_TRY(hipSetDevice(r->device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(hipMemcpy(out, r->pool_tuning.stats, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(r->pool_tuning.stats, 0, 32 * sizeof(uint64_t)));
     return DRT_OK;
 }
 

@@ -40,7 +40,7 @@ namespace {
 constexpr int kNQ = 7;                               // queues: N, T0..T3, B, E
 enum : int { QN = 0, QT0 = 1, QB = 5, QE = 6 };
 constexpr uint32_t kEmptyId = 0xFFFFu;
-constexpr uint32_t kHasSample = 1u << 16;            // quadC.w: bounce index (low 16 bits) | flags
+constexpr uint32_t kHasSample = 1u << 16;            // quad D.w: bounce index (low 16 bits) | flags
 constexpr int kMaxPoolThreads = 1024;                // up to 16 waves per workgroup = 4 per SIMD (128 VGPRs each)
 
 typedef uint32_t pp_u32x4 __attribute__((ext_vector_type(4)));
@@ -96,7 +96,7 @@ __host__ __device__ inline PoolLayout pool_layout(uint32_t P, uint32_t ring_cap,
     l.ctrl = 0;                                     // head/tail pairs of the kNQ queues (8 B each), then live, abort, exhausted
     l.rings = 128;
     l.quads = l.rings + (uint32_t)kNQ * ring_cap * 2u;
-    l.stack = l.quads + 5u * P * 16u;
+    l.stack = l.quads + 3u * P * 16u;       // A {origin, hit_t}  B {direction, leaf range | stack height}  D {hit u, v, triangle, bounce | flags}
     l.scene = l.stack + stack_entries * P * 8u;
     l.total = l.scene + scene_bytes;
     return l;
@@ -113,10 +113,15 @@ struct PoolParams {
     uint32_t t_class[3];       // leaf step counts (two triangles per step) up to t_class[i] wait in queue T<i>; larger ones in T3
     uint32_t min_fill;         // a wave prefers waiting to running a batch thinner than this ...
     uint32_t patience;         // ... for this many polls
+    uint32_t n_loop;           // N: at most this many pops per batch ...
+    uint32_t n_min_lanes;      // ... and the batch ends when fewer lanes than this are still popping (the rest go back to N)
+    uint4 *aux;                // HBM, [workgroup][path]: {throughput, seed} -- what only B and E touch stays out of LDS
+    uint32_t *aux_slot;        // HBM, [workgroup][path]: where the path's sample goes in `samples`
     unsigned int *status;      // device word: != 0 after an aborted launch
+    unsigned long long *stats; // STATS build: per queue {batches, lanes, ticks} (3 x kNQ), then claim ticks, idle polls, lost claims, wave ticks
 };
 
-template <bool DUMMY>
+template <bool STATS>
 __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneView sc, const FrameParams fp, const PoolParams pp,
                                                                     unsigned int *sample_counter, float4 *samples) {
     extern __shared__ uint4 lds_raw[];
@@ -130,7 +135,9 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds_raw);      // low 32 bits of the flat address = LDS offset
     const uint32_t ctrl = lds_base + lay.ctrl, rings = lds_base + lay.rings, quads = lds_base + lay.quads, stack = lds_base + lay.stack;
     const uint32_t lds_inner = lds_base + lay.scene, lds_hot = lds_inner + sc.n_inner * 64u, lds_leaf = lds_hot + sc.n_tris * 48u;
-    const uint32_t qA = quads, qB = quads + P * 16u, qC = quads + 2u * P * 16u, qD = quads + 3u * P * 16u, qE = quads + 4u * P * 16u;
+    const uint32_t qA = quads, qB = quads + P * 16u, qD = quads + 2u * P * 16u;
+    uint4 *const aux = pp.aux + (size_t)blockIdx.x * P;
+    uint32_t *const aux_slot = pp.aux_slot + (size_t)blockIdx.x * P;
 
     if (fp.span && lane == 0) atomicMax(&fp.span[0], ~(unsigned long long)wall_clock64());
 
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         for (uint32_t i = tid; i < sc.n_leaves; i += wg) st2(lds_leaf + i * 8u, make_uint2((uint32_t)sc.leaves[i].start, (uint32_t)sc.leaves[i].count));
         for (uint32_t i = tid; i < (uint32_t)kNQ * pp.ring_cap; i += wg) st_id(rings + i * 2u, kEmptyId);
         for (uint32_t i = tid; i < 32u; i += wg) st1(ctrl + i * 4u, 0u);
-        for (uint32_t i = tid; i < P; i += wg) st1(qC + i * 16u + 12u, 0u);            // no sample yet
+        for (uint32_t i = tid; i < P; i += wg) st1(qD + i * 16u + 12u, 0u);            // no sample yet
         __syncthreads();
         for (uint32_t i = tid; i < P; i += wg) st_id(rings + ((uint32_t)QE * pp.ring_cap + i) * 2u, i);
         if (tid == 0) { st1(ctrl + QE * 8u + 4u, P); st1(ctrl + kCtrlLive, P); }
@@ -180,9 +187,50 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     };
     // traversal over: a path with a hit is shaded (B), one without ends on the sky (E)
     auto after_traversal = [&](float hit_t) -> int { return hit_t < FLT_MAX ? QB : QE; };
-    auto push = [&](int q, uint32_t id) {
-        const uint32_t pos = lds_add(ctrl + (uint32_t)q * 8u + 4u, 1u);
-        st_id(rings + ((uint32_t)q * pp.ring_cap + (pos & ring_mask)) * 2u, id);
+    // One pop of BVHTraversal.cuh:33-72 for a path whose stack holds sp > 0 entries.  Returns the T queue when the path now
+    // stands on a leaf (packed = its triangle range + stack height), else -1 (popped entry culled, or an interior node whose
+    // children went on the stack).  (ray.dir is not used: the slab test needs the origin and 1/dir.)
+    auto pop_step = [&](const Ray &ray, float hit_t, int &sp, uint32_t id, uint32_t &packed) -> int {
+        --sp;
+        const uint2 e = ld2(stack + ((uint32_t)sp * P + id) * 8u);
+        int dest = -1;
+        // :41 (without a hit, hit_t = FLT_MAX > dist); :38 was applied when the root was pushed
+        if (!(hit_t < u2f(e.y))) {
+            if (e.x & kLeafBit) dest = leaf_state(e.x & ~kLeafBit, sp, packed);
+            else {
+                const ChildPair c = fetch_children(e.x);
+                const float d1 = slab_entry_or_inf(c.min1, c.max1, ray);
+                const float d2 = slab_entry_or_inf(c.min2, c.max2, ray);
+                const bool first_is_1 = d1 > d2;          // farther child first; child 2 first on ties (:63-70)
+                const uint32_t ra = first_is_1 ? c.ref1 : c.ref2, rb = first_is_1 ? c.ref2 : c.ref1;
+                const float da = first_is_1 ? d1 : d2, db = first_is_1 ? d2 : d1;
+                if (da < hit_t) { st2(stack + ((uint32_t)sp * P + id) * 8u, make_uint2(ra, f2u(da))); ++sp; }
+                if (db < hit_t) {
+                    // a near child that is a leaf is this path's next visit and passes :41 (nothing changes hit_t in between)
+                    if (rb & kLeafBit) dest = leaf_state(rb & ~kLeafBit, sp, packed);
+                    else { st2(stack + ((uint32_t)sp * P + id) * 8u, make_uint2(rb, f2u(db))); ++sp; }
+                }
+            }
+        }
+        return dest;
+    };
+    // Push every lane's path id (dest >= 0) to its destination queue: one atomic add per destination present in the wave
+    // (issued together by the first lane of each group), then the ids go to consecutive ring positions.
+    auto push_group = [&](int dest, uint32_t id) {
+        unsigned long long todo = pp_ballot(dest >= 0);
+        uint32_t add_count = 0, my_rank = 0;
+        int my_leader = 0;
+        while (todo) {
+            const int first = __builtin_ctzll(todo);
+            const int d = __builtin_amdgcn_readlane(dest, first);
+            const unsigned long long m = pp_ballot(dest == d);
+            if (dest == d) { my_rank = (uint32_t)pp_rank(m); my_leader = first; add_count = (uint32_t)__popcll(m); }
+            todo &= ~m;
+        }
+        uint32_t base = 0;
+        if (dest >= 0 && lane == my_leader) base = lds_add(ctrl + (uint32_t)dest * 8u + 4u, add_count);
+        base = (uint32_t)__builtin_amdgcn_ds_bpermute(my_leader << 2, (int)base);
+        if (dest >= 0) st_id(rings + ((uint32_t)dest * pp.ring_cap + ((base + my_rank) & ring_mask)) * 2u, id);
     };
     const f3 root_min = ld3(sc.root_min), root_max = ld3(sc.root_max);
     // TraceRay.cu:15-20 + BVHTraversal.cuh:22-26,38: the root goes on the stack with its slab distance when -1 < d < FLT_MAX
@@ -193,35 +241,60 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         st2(stack + id * 8u, make_uint2(sc.root_ref, f2u(d)));
         return 1;
     };
-    auto store_new_ray = [&](uint32_t id, const Ray &ray, int sp, uint32_t bounce_flags, uint32_t seed) {
+    // A new ray: root on the stack, first pop done right away (every lane of the batch needs it), state stored.
+    // Returns the queue the path goes to.
+    auto launch_ray = [&](uint32_t id, const Ray &ray, uint32_t bounce_flags, bool trace) -> int {
+        int sp = trace ? begin_closest(ray, id) : 0;
+        uint32_t packed = 0;
+        int dest = -1;
+        if (sp > 0) dest = pop_step(ray, FLT_MAX, sp, id, packed);
+        if (dest < 0) { packed = (uint32_t)sp << 24; dest = sp > 0 ? QN : QE; }       // QE: the ray missed the scene's bounds -> sky
         st4(qA + id * 16u, make_uint4(f2u(ray.orig.x), f2u(ray.orig.y), f2u(ray.orig.z), f2u(FLT_MAX)));
-        st4(qB + id * 16u, make_uint4(f2u(ray.dir.x), f2u(ray.dir.y), f2u(ray.dir.z), (uint32_t)sp << 24));
-        st4(qC + id * 16u, make_uint4(f2u(ray.inv_dir.x), f2u(ray.inv_dir.y), f2u(ray.inv_dir.z), bounce_flags));
-        st4(qD + id * 16u, make_uint4(0u, 0u, 0xFFFFFFFFu, seed));
+        st4(qB + id * 16u, make_uint4(f2u(ray.dir.x), f2u(ray.dir.y), f2u(ray.dir.z), packed));
+        st4(qD + id * 16u, make_uint4(0u, 0u, 0xFFFFFFFFu, bounce_flags));
+        return dest;
     };
 
-    uint32_t polls = 0, idle_polls = 0;
+    const int wave = tid >> 6;
+    uint32_t polls = 0, idle_polls = 0, rot = (uint32_t)wave;
+    unsigned long long s_batches[kNQ], s_lanes[kNQ], s_ticks[kNQ], s_claim = 0, s_idle = 0, s_lost = 0;
+    for (int k = 0; k < kNQ; k++) s_batches[k] = s_lanes[k] = s_ticks[k] = 0;
+    const unsigned long long s_t_start = STATS ? __builtin_amdgcn_s_memtime() : 0;
+    unsigned long long s_t0 = s_t_start;
     for (;;) {
-        // ---------------- choose a queue: the fullest one; claim up to 64 of its ids ----------------
+        if (STATS) s_t0 = __builtin_amdgcn_s_memtime();
+        // ---------------- choose a queue and claim up to 64 of its ids ----------------
+        // Queues holding a full batch are shared out round robin (the waves of a workgroup would otherwise all race for
+        // the same one); with none, the fullest queue is taken -- after a short wait for company unless the launch is draining.
         uint32_t my_head = 0, my_tail = 0;
         if (lane < kNQ) { my_head = ld1_shared(ctrl + (uint32_t)lane * 8u); my_tail = ld1_shared(ctrl + (uint32_t)lane * 8u + 4u); }
         const int my_avail = (int)(my_tail - my_head);
         int q = -1, avail = 0;
+        const unsigned full_mask = (unsigned)pp_ballot(my_avail >= 64) & ((1u << kNQ) - 1u);
+        if (full_mask) {
+            int pick = (int)(rot % (uint32_t)__popc(full_mask));
+            unsigned mm = full_mask;
+            while (pick-- > 0) mm &= mm - 1u;
+            q = __builtin_ctz(mm);
+            avail = 64;
+        } else {
 #pragma unroll
-        for (int k = 0; k < kNQ; k++) {
-            const int a = __builtin_amdgcn_readlane(my_avail, k);
-            if (a > avail) { avail = a; q = k; }
+            for (int k = 0; k < kNQ; k++) {
+                const int a = __builtin_amdgcn_readlane(my_avail, k);
+                if (a > avail) { avail = a; q = k; }
+            }
         }
-        const bool aborted = ld1_shared(ctrl + kCtrlAbort) != 0;
-        if (aborted) break;
+        if (ld1_shared(ctrl + kCtrlAbort) != 0) break;
         if (q < 0) {
             if (ld1_shared(ctrl + kCtrlLive) == 0) break;                 // every pool slot retired: the launch is done
             __builtin_amdgcn_s_sleep(8);
+            if (STATS) s_idle++;
             if (++idle_polls > (1u << 22)) { st1_shared(ctrl + kCtrlAbort, 1u); if (lane == 0 && pp.status) atomicOr(pp.status, 1u); break; }
             continue;
         }
         if ((uint32_t)avail < pp.min_fill && polls < pp.patience && ld1_shared(ctrl + kCtrlExhausted) == 0) {
             ++polls;
+            if (STATS) s_idle++;
             __builtin_amdgcn_s_sleep(2);
             continue;
         }
@@ -230,7 +303,8 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         int won = 0;
         if (lane == 0) won = lds_cas(ctrl + (uint32_t)q * 8u, head, head + n) ? 1 : 0;
         won = __builtin_amdgcn_readfirstlane(won);
-        if (!won) continue;                                               // another wave was faster: look again
+        ++rot;
+        if (!won) { if (STATS) s_lost++; continue; }                      // another wave was faster: look again
         polls = 0; idle_polls = 0;
         const bool active = (uint32_t)lane < n;
         uint32_t id = 0;
@@ -245,54 +319,45 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             st_id(at, kEmptyId);
         }
         lds_acquire();
+        unsigned long long s_t1 = 0;
+        if (STATS) { s_t1 = __builtin_amdgcn_s_memtime(); s_claim += s_t1 - s_t0; s_batches[q]++; s_lanes[q] += n; }
+        int dest = -1;                                                    // queue this lane's path goes to next
 
         if (q == QN) {
-            // ============ N: pop one stack entry (BVHTraversal.cuh:33-72) ============
+            // ============ N: pop stack entries until the path stands on a leaf (BVHTraversal.cuh:33-72) ============
+            Ray ray = make_ray(mk3(0, 0, 0), mk3(0, 0, 1));
+            float hit_t = FLT_MAX;
+            int sp = 0;
+            uint32_t packed = 0;
             if (active) {
-                const uint4 A = ld4(qA + id * 16u), C = ld4(qC + id * 16u);
-                int sp = (int)(ld1(qB + id * 16u + 12u) >> 24);
-                const float hit_t = u2f(A.w);
-                Ray ray; ray.orig = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); ray.inv_dir = mk3(u2f(C.x), u2f(C.y), u2f(C.z)); ray.dir = ray.inv_dir;   // (dir is not used by the slab test)
-                --sp;
-                const uint2 e = ld2(stack + ((uint32_t)sp * P + id) * 8u);
-                uint32_t packed = (uint32_t)sp << 24;
-                int dest = -1;
-                // :41 (without a hit, hit_t = FLT_MAX > dist); :38 was applied when the root was pushed
-                if (!(hit_t < u2f(e.y))) {
-                    if (e.x & kLeafBit) dest = leaf_state(e.x & ~kLeafBit, sp, packed);
-                    else {
-                        const ChildPair c = fetch_children(e.x);
-                        const float d1 = slab_entry_or_inf(c.min1, c.max1, ray);
-                        const float d2 = slab_entry_or_inf(c.min2, c.max2, ray);
-                        const bool first_is_1 = d1 > d2;          // farther child first; child 2 first on ties (:63-70)
-                        const uint32_t ra = first_is_1 ? c.ref1 : c.ref2, rb = first_is_1 ? c.ref2 : c.ref1;
-                        const float da = first_is_1 ? d1 : d2, db = first_is_1 ? d2 : d1;
-                        if (da < hit_t) { st2(stack + ((uint32_t)sp * P + id) * 8u, make_uint2(ra, f2u(da))); ++sp; }
-                        packed = (uint32_t)sp << 24;
-                        if (db < hit_t) {
-                            // a near child that is a leaf is this path's next visit and passes :41 (nothing changes hit_t in between)
-                            if (rb & kLeafBit) dest = leaf_state(rb & ~kLeafBit, sp, packed);
-                            else { st2(stack + ((uint32_t)sp * P + id) * 8u, make_uint2(rb, f2u(db))); ++sp; packed = (uint32_t)sp << 24; }
-                        }
-                    }
-                }
+                const uint4 A = ld4(qA + id * 16u), B = ld4(qB + id * 16u);
+                sp = (int)(B.w >> 24);
+                hit_t = u2f(A.w);
+                ray = make_ray(mk3(u2f(A.x), u2f(A.y), u2f(A.z)), mk3(u2f(B.x), u2f(B.y), u2f(B.z)));     // 1/dir again (Ray.cuh:7-9): 12 bytes of LDS per path saved
+            }
+            for (uint32_t it = 0;; ++it) {
+                const bool go = active && dest < 0 && sp > 0;
+                const unsigned long long m_go = pp_ballot(go);
+                // lanes that are done wait for the others only while enough of them are still popping
+                if (m_go == 0 || it >= pp.n_loop || (it > 0 && (uint32_t)__popcll(m_go) < pp.n_min_lanes)) break;
+                if (go) dest = pop_step(ray, hit_t, sp, id, packed);
+            }
+            if (active) {
+                if (dest < 0) { packed = (uint32_t)sp << 24; dest = sp > 0 ? QN : after_traversal(hit_t); }
                 st1(qB + id * 16u + 12u, packed);
-                if (dest < 0) dest = sp > 0 ? QN : after_traversal(hit_t);
-                lds_release();
-                push(dest, id);
             }
         } else if (q >= QT0 && q < QB) {
             // ============ T: the triangles of one leaf, two per step (Intersection.cu:4-36, BVHTraversal.cuh:46-57) ============
             Ray ray = make_ray(mk3(0, 0, 0), mk3(0, 0, 1));
             float hit_t = FLT_MAX, hit_u = 0, hit_v = 0;
-            uint32_t hit_prim = 0xFFFFFFFFu, seed_keep = 0;
+            uint32_t hit_prim = 0xFFFFFFFFu, flags_keep = 0;
             int cur = 0, end = 0, sp = 0;
             if (active) {
                 const uint4 A = ld4(qA + id * 16u), B = ld4(qB + id * 16u), D = ld4(qD + id * 16u);
                 ray.orig = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); hit_t = u2f(A.w);
                 ray.dir = mk3(u2f(B.x), u2f(B.y), u2f(B.z));
                 cur = (int)(B.w & 0xFFFu); end = (int)((B.w >> 12) & 0xFFFu); sp = (int)(B.w >> 24);
-                hit_u = u2f(D.x); hit_v = u2f(D.y); hit_prim = D.z; seed_keep = D.w;
+                hit_u = u2f(D.x); hit_v = u2f(D.y); hit_prim = D.z; flags_keep = D.w;
             }
             const float hit_t_in = hit_t;
             while (pp_ballot(cur < end) != 0) {
@@ -312,22 +377,31 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             if (active) {
                 if (hit_t < hit_t_in) {
                     st1(qA + id * 16u + 12u, f2u(hit_t));
-                    st4(qD + id * 16u, make_uint4(f2u(hit_u), f2u(hit_v), hit_prim, seed_keep));
+                    st4(qD + id * 16u, make_uint4(f2u(hit_u), f2u(hit_v), hit_prim, flags_keep));
                 }
-                st1(qB + id * 16u + 12u, (uint32_t)sp << 24);
-                lds_release();
-                push(sp > 0 ? QN : after_traversal(hit_t), id);
+                // What the next pops would do while the top of the stack is culled (:41) or a leaf: done here, the path goes
+                // straight to its next leaf; an interior node is left to N.
+                uint32_t packed = 0;
+                while (sp > 0) {
+                    const uint2 e = ld2(stack + ((uint32_t)(sp - 1) * P + id) * 8u);
+                    if (hit_t < u2f(e.y)) { --sp; continue; }
+                    if (e.x & kLeafBit) { --sp; dest = leaf_state(e.x & ~kLeafBit, sp, packed); }
+                    break;
+                }
+                if (dest < 0) { packed = (uint32_t)sp << 24; dest = sp > 0 ? QN : after_traversal(hit_t); }
+                st1(qB + id * 16u + 12u, packed);
             }
         } else if (q == QB) {
             // ============ B: shade the hit, draw the bounce direction, launch the bounce ray (RayGen.cuh:90-134) ============
             if (active) {
-                const uint4 A = ld4(qA + id * 16u), B = ld4(qB + id * 16u), D = ld4(qD + id * 16u), E = ld4(qE + id * 16u);
-                const uint32_t Cw = ld1(qC + id * 16u + 12u);
+                const uint4 E = aux[id];                                                   // {throughput, seed}
+                const uint4 A = ld4(qA + id * 16u), B = ld4(qB + id * 16u), D = ld4(qD + id * 16u);
+                const uint32_t Cw = D.w;
                 Ray ray; ray.orig = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); ray.dir = mk3(u2f(B.x), u2f(B.y), u2f(B.z)); ray.inv_dir = ray.dir;
                 const float hit_t = u2f(A.w), hit_u = u2f(D.x), hit_v = u2f(D.y);
                 const int hit_prim = (int)D.z;
                 int bounce = (int)(Cw & 0xFFFFu);
-                uint32_t seed = D.w + (uint32_t)bounce;                                    // :91
+                uint32_t seed = E.w + (uint32_t)bounce;                                    // :91
                 f3 throughput = mk3(u2f(E.x), u2f(E.y), u2f(E.z));
                 const f3 uvw = mk3(1.0f - hit_u - hit_v, hit_u, hit_v);                    // Intersection.cu:31
                 f3 position, normal;                                                       // ClosestHit.cuh:13-24
@@ -338,34 +412,30 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 else throughput = throughput * tex_get_pixel(sc, sc.texs[mat.tex], interp_uv(cold, uvw));
                 const f3 origin = position + (normal * 0.001f);                            // :121
                 ++bounce;
-                st4(qE + id * 16u, make_uint4(f2u(throughput.x), f2u(throughput.y), f2u(throughput.z), E.w));
-                int dest = QE;
                 if (bounce <= fp.bounce_limit) {                                           // :88 loop condition
                     const f3 p = random_unit_sphere_vec3_try(seed);                        // :133 (Random.cu:50-58)
-                    const Ray next = make_ray(origin, normal + p);                         // :134
-                    const int sp = begin_closest(next, id);
-                    store_new_ray(id, next, sp, (uint32_t)bounce | kHasSample, seed);
-                    if (sp > 0) dest = QN;                                                 // else: missed the scene's bounds -> sky (hit_t = FLT_MAX)
+                    aux[id] = make_uint4(f2u(throughput.x), f2u(throughput.y), f2u(throughput.z), seed);
+                    dest = launch_ray(id, make_ray(origin, normal + p), (uint32_t)bounce | kHasSample, true);   // :134
                 } else {
                     st1(qA + id * 16u + 12u, 0u);        // the path ends without reaching the sky: E adds no light (hit_t != FLT_MAX)
+                    dest = QE;
                 }
-                lds_release();
-                push(dest, id);
             }
         } else {
             // ============ E: finish the path, store its sample; deal a new sample, primary ray (RayGen.cuh:63-108,165-171) ============
-            uint32_t Cw = 0;
             if (active) {
-                Cw = ld1(qC + id * 16u + 12u);
+                const uint32_t Cw = ld1(qD + id * 16u + 12u);
                 if (Cw & kHasSample) {
-                    const uint4 B = ld4(qB + id * 16u), E = ld4(qE + id * 16u);
+                    const uint4 E = aux[id];
+                    const uint32_t slot = aux_slot[id];
+                    const uint4 B = ld4(qB + id * 16u);
                     const float hit_t = u2f(ld1(qA + id * 16u + 12u));
                     f3 light = mk3(0, 0, 0);
                     if (!(hit_t < FLT_MAX))                                                // miss: :99-108
                         light = light + sky_model(mk3(u2f(B.x), u2f(B.y), u2f(B.z)), ld3(fp.sky_color)) * mk3(u2f(E.x), u2f(E.y), u2f(E.z)) * fp.sky_intensity;
                     if (fp.tone_mapping) light = uncharted2_filmic(light, fp.exposure);    // :165-169 (wave-uniform branches)
                     if (fp.gamma_correction) light = gamma_correction(light);
-                    samples[E.w] = make_float4(light.x, light.y, light.z, 0.0f);
+                    samples[slot] = make_float4(light.x, light.y, light.z, 0.0f);
                 }
             }
             // one global atomic per batch hands out the sample ids
@@ -388,7 +458,6 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                     const uint32_t tx = tile - ty * pp.tiles_x;
                     ty = (ty * fp.row_step) % (n_tiles_all / pp.tiles_x);
                     const uint32_t x = tx * 8u + (my_k & 7u), ly = ty * 8u + (my_k >> 3);
-                    int dest = QE;
                     if (x < fp.width && ly < fp.local_rows) {
                         const uint32_t y = ((ly / fp.stripe_rows) * fp.world + fp.rank) * fp.stripe_rows + (ly % fp.stripe_rows);
                         const uint32_t slot = f_rel * (fp.width * fp.local_rows) + ly * fp.width + x;
@@ -398,23 +467,28 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                         uint32_t seed = x + y * fp.width;
                         seed *= fp.frame_first + f_rel;
                         const Ray ray = camera_get_ray(fp, screen_uv, seed);
-                        int sp = 0;
-                        if (fp.bounce_limit >= 0) sp = begin_closest(ray, id);
-                        store_new_ray(id, ray, sp, kHasSample, seed);
-                        st4(qE + id * 16u, make_uint4(f2u(1.0f), f2u(1.0f), f2u(1.0f), slot));
+                        dest = launch_ray(id, ray, kHasSample, fp.bounce_limit >= 0);
+                        aux[id] = make_uint4(f2u(1.0f), f2u(1.0f), f2u(1.0f), seed);
+                        aux_slot[id] = slot;
                         if (fp.bounce_limit < 0) st1(qA + id * 16u + 12u, 0u);            // RayGen.cuh:88: the loop body never runs, the sample is black
-                        if (sp > 0) dest = QN;
                     } else {
-                        st1(qC + id * 16u + 12u, 0u);       // a sample id outside the image (partial tile): the slot asks again
+                        st1(qD + id * 16u + 12u, 0u);       // a sample id outside the image (partial tile): the slot asks again
+                        dest = QE;
                     }
-                    lds_release();
-                    push(dest, id);
                 }
             }
         }
+        lds_release();
+        push_group(dest, id);
+        if (STATS) s_ticks[q] += __builtin_amdgcn_s_memtime() - s_t1;
     }
 
     if (fp.span && lane == 0) atomicMax(&fp.span[1], (unsigned long long)wall_clock64());
+    if (STATS && pp.stats && lane == 0) {
+        for (int k = 0; k < kNQ; k++) { atomicAdd(&pp.stats[3 * k], s_batches[k]); atomicAdd(&pp.stats[3 * k + 1], s_lanes[k]); atomicAdd(&pp.stats[3 * k + 2], s_ticks[k]); }
+        atomicAdd(&pp.stats[3 * kNQ], s_claim); atomicAdd(&pp.stats[3 * kNQ + 1], s_idle); atomicAdd(&pp.stats[3 * kNQ + 2], s_lost);
+        atomicAdd(&pp.stats[3 * kNQ + 3], __builtin_amdgcn_s_memtime() - s_t_start);
+    }
 }
 
 }  // namespace
@@ -456,8 +530,8 @@ bool path_pool_supports(const SceneView &sc, const FrameParams &fp, int bvh_dept
 }
 
 hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_depth, const uint32_t t_class[3], const PoolTuning &tune,
-                            unsigned int *sample_counter, void *samples, unsigned int *status, int num_cus, hipStream_t stream,
-                            const char **kernel_name, int *launch_shape) {
+                            PoolScratch &scratch, unsigned int *sample_counter, void *samples, unsigned int *status, int num_cus,
+                            hipStream_t stream, const char **kernel_name, int *launch_shape) {
     if (fp.width == 0 || fp.local_rows == 0 || fp.n_frames == 0) return hipSuccess;
     const int env_threads = tune.threads, env_paths = tune.paths, env_fill = tune.min_fill, env_patience = tune.patience;
     const uint32_t tiles_x = (fp.width + 7) / 8, tiles_y = (fp.local_rows + 7) / 8;
@@ -479,7 +553,7 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     }
     const PoolLayout lay = pool_layout(P, ring_cap, stack_entries, scene_bytes);
     if (lay.total > 160u * 1024u) return hipErrorInvalidValue;
-    auto kernel = path_pool_kernel<true>;
+    auto kernel = tune.stats ? path_pool_kernel<true> : path_pool_kernel<false>;
     if (lay.total > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total);
         if (e != hipSuccess) return e;
@@ -491,9 +565,23 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     pp.total_samples = (uint32_t)(n_chunks * 64ull); pp.n_chunks = (uint32_t)n_chunks; pp.tiles_x = tiles_x;
     pp.t_class[0] = t_class[0]; pp.t_class[1] = t_class[1]; pp.t_class[2] = t_class[2];
     pp.min_fill = (uint32_t)std::max(1, std::min(env_fill, 64)); pp.patience = (uint32_t)std::max(0, env_patience);
-    pp.status = status;
+    pp.n_loop = (uint32_t)std::max(1, tune.n_loop); pp.n_min_lanes = (uint32_t)std::max(1, std::min(tune.n_min_lanes, 64));
+    pp.status = status; pp.stats = tune.stats;
     // one pool fills with P samples at once: never more workgroups than that leaves work for
     const uint64_t want = std::min<uint64_t>((uint64_t)num_cus * per_cu, std::max<uint64_t>(1, (n_chunks * 64ull + P - 1) / P));
+    // the part of the path state that lives in HBM: 20 bytes per pool slot of every workgroup
+    const size_t slots = (size_t)num_cus * per_cu * P;
+    if (slots > scratch.slots) {
+        if (scratch.aux) (void)hipFree(scratch.aux);
+        if (scratch.aux_slot) (void)hipFree(scratch.aux_slot);
+        scratch.aux = nullptr; scratch.aux_slot = nullptr; scratch.slots = 0;
+        hipError_t ea = hipMalloc(&scratch.aux, slots * 16);
+        if (ea != hipSuccess) return ea;
+        ea = hipMalloc(&scratch.aux_slot, slots * 4);
+        if (ea != hipSuccess) return ea;
+        scratch.slots = slots;
+    }
+    pp.aux = static_cast<uint4 *>(scratch.aux); pp.aux_slot = static_cast<uint32_t *>(scratch.aux_slot);
     hipError_t e = hipMemsetAsync(sample_counter, 0, sizeof(unsigned int), stream);
     if (e != hipSuccess) return e;
     if (kernel_name) *kernel_name = "path_pool<lean,lds-scene>";
