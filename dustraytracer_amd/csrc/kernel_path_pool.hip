@@ -12,9 +12,10 @@
 //     B      shade the closest hit, draw the bounce direction, launch the bounce ray                 RayGen.cuh:90-134
 //     E      finish the path (sky term, tone map, gamma, store the sample), take a new sample,
 //            generate its primary ray                                                               RayGen.cuh:63-108,165-171
-// A wave claims up to 64 path ids of ONE queue (the fullest), loads the part of the state that phase needs (16-byte
-// quads, [quad][path]), runs the phase with every lane busy, stores what changed and pushes each id to the queue of its
-// next phase.  Per-lane order of node visits, triangle tests and RNG draws is the reference's, and the arithmetic is the
+// A wave claims up to 64 path ids of ONE queue, loads the part of the state that phase needs, runs the phase with every
+// lane busy, stores what changed and pushes each id to the queue of its next phase.  State per path: 36 bytes of LDS
+// (A {origin, hit distance}, B {direction, leaf range | stack height}, W {hit triangle | bounce | flag}) + its traversal
+// stack (8 bytes per BVH level); throughput, RNG state and the sample's slot -- touched by B and E only -- live in HBM.  Per-lane order of node visits, triangle tests and RNG draws is the reference's, and the arithmetic is the
 // same device_math.hpp code as wave_queue's, so the image is bit-identical; only who computes what when differs.
 //
 // Queues are rings of 16-bit path ids in LDS, multi-producer / multi-consumer inside the workgroup: a producer reserves a
@@ -40,7 +41,8 @@ namespace {
 constexpr int kNQ = 7;                               // queues: N, T0..T3, B, E
 enum : int { QN = 0, QT0 = 1, QB = 5, QE = 6 };
 constexpr uint32_t kEmptyId = 0xFFFFu;
-constexpr uint32_t kHasSample = 1u << 16;            // quad D.w: bounce index (low 16 bits) | flags
+constexpr uint32_t kNoPrim = 0xFFFu;                 // word W: hit triangle (12 bits, kNoPrim = none) | bounce index << 12 (16 bits) | kHasSample
+constexpr uint32_t kHasSample = 1u << 28;
 constexpr int kMaxPoolThreads = 1024;                // up to 16 waves per workgroup = 4 per SIMD (128 VGPRs each)
 
 typedef uint32_t pp_u32x4 __attribute__((ext_vector_type(4)));
@@ -56,11 +58,21 @@ DRT_DEV void st1(uint32_t off, uint32_t v) { *(PP_LDS(uint32_t) *)off = v; }
 // control words and ring entries are shared between waves: relaxed atomics (never cached in registers), workgroup scope
 DRT_DEV uint32_t ld1_shared(uint32_t off) { return __hip_atomic_load((PP_LDS(uint32_t) *)off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DRT_DEV void st1_shared(uint32_t off, uint32_t v) { __hip_atomic_store((PP_LDS(uint32_t) *)off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DRT_DEV uint2 ld2_shared(uint32_t off) {
+    const unsigned long long v = __hip_atomic_load((PP_LDS(unsigned long long) *)off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
 DRT_DEV uint32_t ld_id(uint32_t off) { return __hip_atomic_load((PP_LDS(unsigned short) *)off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DRT_DEV void st_id(uint32_t off, uint32_t v) { __hip_atomic_store((PP_LDS(unsigned short) *)off, (unsigned short)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DRT_DEV uint32_t lds_add(uint32_t off, uint32_t v) { return __hip_atomic_fetch_add((PP_LDS(uint32_t) *)off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DRT_DEV bool lds_cas(uint32_t off, uint32_t expect, uint32_t desired) {
     return __hip_atomic_compare_exchange_strong((PP_LDS(uint32_t) *)off, &expect, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// compare-and-swap that also reports the value found (the new head, when another wave won the race)
+DRT_DEV bool lds_cas_seen(uint32_t off, uint32_t expect, uint32_t desired, uint32_t &seen) {
+    const bool ok = __hip_atomic_compare_exchange_strong((PP_LDS(uint32_t) *)off, &expect, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    seen = expect;
+    return ok;
 }
 DRT_DEV void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 DRT_DEV void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
@@ -73,10 +85,12 @@ __device__ inline void st2(uint32_t, uint2) {}
 __device__ inline void st1(uint32_t, uint32_t) {}
 __device__ inline uint32_t ld1_shared(uint32_t) { return 0; }
 __device__ inline void st1_shared(uint32_t, uint32_t) {}
+__device__ inline uint2 ld2_shared(uint32_t) { return make_uint2(0, 0); }
 __device__ inline uint32_t ld_id(uint32_t) { return 0; }
 __device__ inline void st_id(uint32_t, uint32_t) {}
 __device__ inline uint32_t lds_add(uint32_t, uint32_t) { return 0; }
 __device__ inline bool lds_cas(uint32_t, uint32_t, uint32_t) { return false; }
+__device__ inline bool lds_cas_seen(uint32_t, uint32_t, uint32_t, uint32_t &) { return false; }
 __device__ inline void lds_release() {}
 __device__ inline void lds_acquire() {}
 #endif
@@ -89,19 +103,23 @@ DRT_DEV uint32_t f2u(float f) { return __float_as_uint(f); }
 
 // LDS map of a workgroup (byte offsets from the start of its dynamic LDS; host and device compute it the same way)
 struct PoolLayout {
-    uint32_t ctrl, rings, quads, stack, scene, total;      // byte offsets; total = bytes needed
+    uint32_t ctrl, rings, quads, words, stack, scene, cold, total;      // byte offsets; total = bytes needed
 };
-__host__ __device__ inline PoolLayout pool_layout(uint32_t P, uint32_t ring_cap, uint32_t stack_entries, uint32_t scene_bytes) {
+__host__ __device__ inline PoolLayout pool_layout(uint32_t P, uint32_t ring_cap, uint32_t stack_entries, uint32_t scene_bytes, uint32_t cold_bytes) {
     PoolLayout l;
-    l.ctrl = 0;                                     // head/tail pairs of the kNQ queues (8 B each), then live, abort, exhausted
+    l.ctrl = 0;                                     // head/tail pairs of the kNQ queues (8 B each), then {live, abort}, {exhausted, -}
     l.rings = 128;
     l.quads = l.rings + (uint32_t)kNQ * ring_cap * 2u;
-    l.stack = l.quads + 3u * P * 16u;       // A {origin, hit_t}  B {direction, leaf range | stack height}  D {hit u, v, triangle, bounce | flags}
-    l.scene = l.stack + stack_entries * P * 8u;
-    l.total = l.scene + scene_bytes;
+    l.words = l.quads + 2u * P * 16u;
+    l.stack = l.words + P * 4u;
+    l.scene = (l.stack + stack_entries * P * 8u + 15u) & ~15u;
+    l.cold = l.scene + scene_bytes;
+    l.total = l.cold + cold_bytes;
     return l;
 }
 constexpr uint32_t kCtrlLive = 64, kCtrlAbort = 68, kCtrlExhausted = 72;
+__host__ __device__ inline uint32_t pool_scene_bytes(const SceneView &sc) { return sc.n_inner * 64u + sc.n_tris * 48u + ((sc.n_leaves * 8u + 15u) & ~15u); }
+__host__ __device__ inline uint32_t pool_cold_bytes(const SceneView &sc) { return sc.n_tris * 32u + sc.n_mats * 16u + sc.n_texs * 16u; }
 
 // What the host decides per launch (next to FrameParams)
 struct PoolParams {
@@ -115,6 +133,7 @@ struct PoolParams {
     uint32_t patience;         // ... for this many polls
     uint32_t n_loop;           // N: at most this many pops per batch ...
     uint32_t n_min_lanes;      // ... and the batch ends when fewer lanes than this are still popping (the rest go back to N)
+    uint32_t cold_in_lds;      // TriCold / MatDev / TexDev records staged in LDS too (small scenes): B's loads chain through LDS
     uint4 *aux;                // HBM, [workgroup][path]: {throughput, seed} -- what only B and E touch stays out of LDS
     uint32_t *aux_slot;        // HBM, [workgroup][path]: where the path's sample goes in `samples`
     unsigned int *status;      // device word: != 0 after an aborted launch
@@ -130,12 +149,13 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     const uint32_t wg = blockDim.x;
     const uint32_t P = pp.P;
     const uint32_t ring_mask = pp.ring_cap - 1u;
-    const uint32_t scene_bytes = sc.n_inner * 64u + sc.n_tris * 48u + ((sc.n_leaves * 8u + 15u) & ~15u);
-    const PoolLayout lay = pool_layout(P, pp.ring_cap, pp.stack_entries, scene_bytes);
+    const bool cold_lds = pp.cold_in_lds != 0;
+    const PoolLayout lay = pool_layout(P, pp.ring_cap, pp.stack_entries, pool_scene_bytes(sc), cold_lds ? pool_cold_bytes(sc) : 0u);
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds_raw);      // low 32 bits of the flat address = LDS offset
-    const uint32_t ctrl = lds_base + lay.ctrl, rings = lds_base + lay.rings, quads = lds_base + lay.quads, stack = lds_base + lay.stack;
+    const uint32_t ctrl = lds_base + lay.ctrl, rings = lds_base + lay.rings, stack = lds_base + lay.stack;
+    const uint32_t qA = lds_base + lay.quads, qB = qA + P * 16u, qW = lds_base + lay.words;
     const uint32_t lds_inner = lds_base + lay.scene, lds_hot = lds_inner + sc.n_inner * 64u, lds_leaf = lds_hot + sc.n_tris * 48u;
-    const uint32_t qA = quads, qB = quads + P * 16u, qD = quads + 2u * P * 16u;
+    const uint32_t lds_cold = lds_base + lay.cold, lds_mats = lds_cold + sc.n_tris * 32u, lds_texs = lds_mats + sc.n_mats * 16u;
     uint4 *const aux = pp.aux + (size_t)blockIdx.x * P;
     uint32_t *const aux_slot = pp.aux_slot + (size_t)blockIdx.x * P;
 
@@ -148,9 +168,17 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         for (uint32_t i = tid; i < sc.n_inner * 4u; i += wg) st4(lds_inner + i * 16u, g_inner[i]);
         for (uint32_t i = tid; i < sc.n_tris * 3u; i += wg) st4(lds_hot + i * 16u, g_hot[i]);
         for (uint32_t i = tid; i < sc.n_leaves; i += wg) st2(lds_leaf + i * 8u, make_uint2((uint32_t)sc.leaves[i].start, (uint32_t)sc.leaves[i].count));
+        if (cold_lds) {
+            const uint4 *g_cold = reinterpret_cast<const uint4 *>(sc.tri_cold);
+            const uint4 *g_mats = reinterpret_cast<const uint4 *>(sc.mats);
+            const uint4 *g_texs = reinterpret_cast<const uint4 *>(sc.texs);
+            for (uint32_t i = tid; i < sc.n_tris * 2u; i += wg) st4(lds_cold + i * 16u, g_cold[i]);
+            for (uint32_t i = tid; i < sc.n_mats; i += wg) st4(lds_mats + i * 16u, g_mats[i]);
+            for (uint32_t i = tid; i < sc.n_texs; i += wg) st4(lds_texs + i * 16u, g_texs[i]);
+        }
         for (uint32_t i = tid; i < (uint32_t)kNQ * pp.ring_cap; i += wg) st_id(rings + i * 2u, kEmptyId);
         for (uint32_t i = tid; i < 32u; i += wg) st1(ctrl + i * 4u, 0u);
-        for (uint32_t i = tid; i < P; i += wg) st1(qD + i * 16u + 12u, 0u);            // no sample yet
+        for (uint32_t i = tid; i < P; i += wg) st1(qW + i * 4u, kNoPrim);               // no sample yet
         __syncthreads();
         for (uint32_t i = tid; i < P; i += wg) st_id(rings + ((uint32_t)QE * pp.ring_cap + i) * 2u, i);
         if (tid == 0) { st1(ctrl + QE * 8u + 4u, P); st1(ctrl + kCtrlLive, P); }
@@ -176,6 +204,27 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     auto fetch_face_normal = [&](int prim) -> f3 {
         const uint32_t q = lds_hot + __umul24((uint32_t)prim, 48u) + 36u;
         return mk3(u2f(ld1(q)), u2f(ld1(q + 4)), u2f(ld1(q + 8)));
+    };
+    auto fetch_cold = [&](int prim) -> TriCold {
+        if (!cold_lds) return sc.tri_cold[prim];
+        const uint32_t q = lds_cold + (uint32_t)prim * 32u;
+        const uint4 a = ld4(q), b = ld4(q + 16);
+        TriCold c;
+        c.uv[0][0] = u2f(a.x); c.uv[0][1] = u2f(a.y); c.uv[1][0] = u2f(a.z); c.uv[1][1] = u2f(a.w);
+        c.uv[2][0] = u2f(b.x); c.uv[2][1] = u2f(b.y); c.material = (int32_t)b.z; c._pad = 0;
+        return c;
+    };
+    auto fetch_mat = [&](int index) -> MatDev {
+        if (!cold_lds) return sc.mats[index];
+        const uint4 a = ld4(lds_mats + (uint32_t)index * 16u);
+        MatDev m; m.albedo[0] = u2f(a.x); m.albedo[1] = u2f(a.y); m.albedo[2] = u2f(a.z); m.tex = (int32_t)a.w;
+        return m;
+    };
+    auto fetch_tex = [&](int index) -> TexDev {
+        if (!cold_lds) return sc.texs[index];
+        const uint4 a = ld4(lds_texs + (uint32_t)index * 16u);
+        TexDev t; t.width = (int32_t)a.x; t.height = (int32_t)a.y; t.comps = (int32_t)a.z; t.offset = a.w;
+        return t;
     };
     // leaf -> (first triangle, end) packed with the stack height, and the T queue of its size class
     auto leaf_state = [&](uint32_t leaf_id, int sp, uint32_t &packed) -> int {
@@ -243,7 +292,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     };
     // A new ray: root on the stack, first pop done right away (every lane of the batch needs it), state stored.
     // Returns the queue the path goes to.
-    auto launch_ray = [&](uint32_t id, const Ray &ray, uint32_t bounce_flags, bool trace) -> int {
+    auto launch_ray = [&](uint32_t id, const Ray &ray, uint32_t bounce, bool trace) -> int {
         int sp = trace ? begin_closest(ray, id) : 0;
         uint32_t packed = 0;
         int dest = -1;
@@ -251,7 +300,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         if (dest < 0) { packed = (uint32_t)sp << 24; dest = sp > 0 ? QN : QE; }       // QE: the ray missed the scene's bounds -> sky
         st4(qA + id * 16u, make_uint4(f2u(ray.orig.x), f2u(ray.orig.y), f2u(ray.orig.z), f2u(FLT_MAX)));
         st4(qB + id * 16u, make_uint4(f2u(ray.dir.x), f2u(ray.dir.y), f2u(ray.dir.z), packed));
-        st4(qD + id * 16u, make_uint4(0u, 0u, 0xFFFFFFFFu, bounce_flags));
+        st1(qW + id * 4u, kNoPrim | (bounce << 12) | kHasSample);
         return dest;
     };
 
@@ -266,9 +315,12 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         // ---------------- choose a queue and claim up to 64 of its ids ----------------
         // Queues holding a full batch are shared out round robin (the waves of a workgroup would otherwise all race for
         // the same one); with none, the fullest queue is taken -- after a short wait for company unless the launch is draining.
-        uint32_t my_head = 0, my_tail = 0;
-        if (lane < kNQ) { my_head = ld1_shared(ctrl + (uint32_t)lane * 8u); my_tail = ld1_shared(ctrl + (uint32_t)lane * 8u + 4u); }
-        const int my_avail = (int)(my_tail - my_head);
+        // One LDS read fetches every control word: lanes 0..6 their queue's {head, tail}, lane 8 {live, abort}, lane 9 {exhausted}.
+        uint2 my_ctrl = make_uint2(0u, 0u);
+        if (lane < 10) my_ctrl = ld2_shared(ctrl + (uint32_t)lane * 8u);
+        const int my_avail = lane < kNQ ? (int)(my_ctrl.y - my_ctrl.x) : 0;
+        const uint32_t live = (uint32_t)__builtin_amdgcn_readlane((int)my_ctrl.x, 8), aborted = (uint32_t)__builtin_amdgcn_readlane((int)my_ctrl.y, 8);
+        const uint32_t exhausted = (uint32_t)__builtin_amdgcn_readlane((int)my_ctrl.x, 9);
         int q = -1, avail = 0;
         const unsigned full_mask = (unsigned)pp_ballot(my_avail >= 64) & ((1u << kNQ) - 1u);
         if (full_mask) {
@@ -284,27 +336,38 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 if (a > avail) { avail = a; q = k; }
             }
         }
-        if (ld1_shared(ctrl + kCtrlAbort) != 0) break;
+        if (aborted != 0) break;
         if (q < 0) {
-            if (ld1_shared(ctrl + kCtrlLive) == 0) break;                 // every pool slot retired: the launch is done
+            if (live == 0) break;                                         // every pool slot retired: the launch is done
             __builtin_amdgcn_s_sleep(8);
             if (STATS) s_idle++;
             if (++idle_polls > (1u << 22)) { st1_shared(ctrl + kCtrlAbort, 1u); if (lane == 0 && pp.status) atomicOr(pp.status, 1u); break; }
             continue;
         }
-        if ((uint32_t)avail < pp.min_fill && polls < pp.patience && ld1_shared(ctrl + kCtrlExhausted) == 0) {
+        if ((uint32_t)avail < pp.min_fill && polls < pp.patience && exhausted == 0) {
             ++polls;
             if (STATS) s_idle++;
             __builtin_amdgcn_s_sleep(2);
             continue;
         }
-        const uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)my_head, q);
-        const uint32_t n = (uint32_t)min(avail, 64);
+        uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)my_ctrl.x, q);
+        const uint32_t tail = (uint32_t)__builtin_amdgcn_readlane((int)my_ctrl.y, q);
+        uint32_t n = (uint32_t)min(avail, 64);
         int won = 0;
-        if (lane == 0) won = lds_cas(ctrl + (uint32_t)q * 8u, head, head + n) ? 1 : 0;
-        won = __builtin_amdgcn_readfirstlane(won);
+        // compare-and-swap on the head; a wave that loses the race knows the new head and tries again for what is left
+        for (int attempt = 0; attempt < 4 && !won; attempt++) {
+            uint32_t seen = head;
+            if (lane == 0) won = lds_cas_seen(ctrl + (uint32_t)q * 8u, head, head + n, seen) ? 1 : 0;
+            won = __builtin_amdgcn_readfirstlane(won);
+            if (won) break;
+            if (STATS) s_lost++;
+            head = (uint32_t)__builtin_amdgcn_readfirstlane((int)seen);
+            const int left = (int)(tail - head);
+            if (left < (int)pp.min_fill) break;
+            n = (uint32_t)min(left, 64);
+        }
         ++rot;
-        if (!won) { if (STATS) s_lost++; continue; }                      // another wave was faster: look again
+        if (!won) continue;                                               // the queue went to other waves: look again
         polls = 0; idle_polls = 0;
         const bool active = (uint32_t)lane < n;
         uint32_t id = 0;
@@ -349,15 +412,14 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         } else if (q >= QT0 && q < QB) {
             // ============ T: the triangles of one leaf, two per step (Intersection.cu:4-36, BVHTraversal.cuh:46-57) ============
             Ray ray = make_ray(mk3(0, 0, 0), mk3(0, 0, 1));
-            float hit_t = FLT_MAX, hit_u = 0, hit_v = 0;
-            uint32_t hit_prim = 0xFFFFFFFFu, flags_keep = 0;
+            float hit_t = FLT_MAX;
+            uint32_t hit_prim = kNoPrim;
             int cur = 0, end = 0, sp = 0;
             if (active) {
-                const uint4 A = ld4(qA + id * 16u), B = ld4(qB + id * 16u), D = ld4(qD + id * 16u);
+                const uint4 A = ld4(qA + id * 16u), B = ld4(qB + id * 16u);
                 ray.orig = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); hit_t = u2f(A.w);
                 ray.dir = mk3(u2f(B.x), u2f(B.y), u2f(B.z));
                 cur = (int)(B.w & 0xFFFu); end = (int)((B.w >> 12) & 0xFFFu); sp = (int)(B.w >> 24);
-                hit_u = u2f(D.x); hit_v = u2f(D.y); hit_prim = D.z; flags_keep = D.w;
             }
             const float hit_t_in = hit_t;
             while (pp_ballot(cur < end) != 0) {
@@ -370,14 +432,15 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                     float t0, u0, v0, t1, u1, v1;
                     const bool h0 = tri_intersect_flat(ray, ta.v0, ta.e1, ta.e2, t0, u0, v0);
                     const bool h1 = tri_intersect_flat(ray, tb.v0, tb.e1, tb.e2, t1, u1, v1) & two;
-                    if (h0 && t0 < hit_t) { hit_t = t0; hit_prim = (uint32_t)i; hit_u = u0; hit_v = v0; }
-                    if (h1 && t1 < hit_t) { hit_t = t1; hit_prim = (uint32_t)j; hit_u = u1; hit_v = v1; }
+                    // (the barycentrics are not kept: B computes them again for the one triangle that wins)
+                    if (h0 && t0 < hit_t) { hit_t = t0; hit_prim = (uint32_t)i; }
+                    if (h1 && t1 < hit_t) { hit_t = t1; hit_prim = (uint32_t)j; }
                 }
             }
             if (active) {
                 if (hit_t < hit_t_in) {
                     st1(qA + id * 16u + 12u, f2u(hit_t));
-                    st4(qD + id * 16u, make_uint4(f2u(hit_u), f2u(hit_v), hit_prim, flags_keep));
+                    st1(qW + id * 4u, (ld1(qW + id * 4u) & ~0xFFFu) | hit_prim);
                 }
                 // What the next pops would do while the top of the stack is culled (:41) or a leaf: done here, the path goes
                 // straight to its next leaf; an interior node is left to N.
@@ -395,27 +458,31 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             // ============ B: shade the hit, draw the bounce direction, launch the bounce ray (RayGen.cuh:90-134) ============
             if (active) {
                 const uint4 E = aux[id];                                                   // {throughput, seed}
-                const uint4 A = ld4(qA + id * 16u), B = ld4(qB + id * 16u), D = ld4(qD + id * 16u);
-                const uint32_t Cw = D.w;
+                const uint4 A = ld4(qA + id * 16u), B = ld4(qB + id * 16u);
+                const uint32_t W = ld1(qW + id * 4u);
                 Ray ray; ray.orig = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); ray.dir = mk3(u2f(B.x), u2f(B.y), u2f(B.z)); ray.inv_dir = ray.dir;
-                const float hit_t = u2f(A.w), hit_u = u2f(D.x), hit_v = u2f(D.y);
-                const int hit_prim = (int)D.z;
-                int bounce = (int)(Cw & 0xFFFFu);
-                uint32_t seed = E.w + (uint32_t)bounce;                                    // :91
+                const float hit_t = u2f(A.w);
+                const int hit_prim = (int)(W & 0xFFFu);
+                uint32_t bounce = (W >> 12) & 0xFFFFu;
+                // the barycentrics of the hit: the winning triangle's test once more (same inputs, same bits as in T)
+                float hit_u, hit_v, t_again;
+                const TriTest tri = fetch_tri(hit_prim);
+                (void)tri_intersect_flat(ray, tri.v0, tri.e1, tri.e2, t_again, hit_u, hit_v);
+                uint32_t seed = E.w + bounce;                                              // :91
                 f3 throughput = mk3(u2f(E.x), u2f(E.y), u2f(E.z));
                 const f3 uvw = mk3(1.0f - hit_u - hit_v, hit_u, hit_v);                    // Intersection.cu:31
                 f3 position, normal;                                                       // ClosestHit.cuh:13-24
                 closest_hit_frame(ray, hit_t, fetch_face_normal(hit_prim), position, normal);
-                const TriCold cold = sc.tri_cold[hit_prim];                                // :111-118
-                const MatDev mat = sc.mats[cold.material];
+                const TriCold cold = fetch_cold(hit_prim);                                 // :111-118
+                const MatDev mat = fetch_mat(cold.material);
                 if (mat.tex < 0) throughput = throughput * ld3(mat.albedo);
-                else throughput = throughput * tex_get_pixel(sc, sc.texs[mat.tex], interp_uv(cold, uvw));
+                else throughput = throughput * tex_get_pixel(sc, fetch_tex(mat.tex), interp_uv(cold, uvw));
                 const f3 origin = position + (normal * 0.001f);                            // :121
                 ++bounce;
-                if (bounce <= fp.bounce_limit) {                                           // :88 loop condition
+                if ((int)bounce <= fp.bounce_limit) {                                      // :88 loop condition
                     const f3 p = random_unit_sphere_vec3_try(seed);                        // :133 (Random.cu:50-58)
                     aux[id] = make_uint4(f2u(throughput.x), f2u(throughput.y), f2u(throughput.z), seed);
-                    dest = launch_ray(id, make_ray(origin, normal + p), (uint32_t)bounce | kHasSample, true);   // :134
+                    dest = launch_ray(id, make_ray(origin, normal + p), bounce, true);     // :134
                 } else {
                     st1(qA + id * 16u + 12u, 0u);        // the path ends without reaching the sky: E adds no light (hit_t != FLT_MAX)
                     dest = QE;
@@ -424,8 +491,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         } else {
             // ============ E: finish the path, store its sample; deal a new sample, primary ray (RayGen.cuh:63-108,165-171) ============
             if (active) {
-                const uint32_t Cw = ld1(qD + id * 16u + 12u);
-                if (Cw & kHasSample) {
+                if (ld1(qW + id * 4u) & kHasSample) {
                     const uint4 E = aux[id];
                     const uint32_t slot = aux_slot[id];
                     const uint4 B = ld4(qB + id * 16u);
@@ -467,12 +533,12 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                         uint32_t seed = x + y * fp.width;
                         seed *= fp.frame_first + f_rel;
                         const Ray ray = camera_get_ray(fp, screen_uv, seed);
-                        dest = launch_ray(id, ray, kHasSample, fp.bounce_limit >= 0);
+                        dest = launch_ray(id, ray, 0u, fp.bounce_limit >= 0);
                         aux[id] = make_uint4(f2u(1.0f), f2u(1.0f), f2u(1.0f), seed);
                         aux_slot[id] = slot;
                         if (fp.bounce_limit < 0) st1(qA + id * 16u + 12u, 0u);            // RayGen.cuh:88: the loop body never runs, the sample is black
                     } else {
-                        st1(qD + id * 16u + 12u, 0u);       // a sample id outside the image (partial tile): the slot asks again
+                        st1(qW + id * 4u, kNoPrim);         // a sample id outside the image (partial tile): the slot asks again
                         dest = QE;
                     }
                 }
@@ -524,7 +590,8 @@ void path_pool_leaf_classes(const std::vector<LeafRange> &leaves, uint32_t out[3
 
 bool path_pool_supports(const SceneView &sc, const FrameParams &fp, int bvh_depth, bool scene_has_alpha, size_t scene_lds_bytes) {
     if (fp.render_mode != 0 || fp.enable_sunlight || scene_has_alpha) return false;       // lean paths only (so far)
-    if (scene_lds_bytes > kLdsSceneBytes || sc.n_tris >= 4096u || bvh_depth > 200) return false;
+    if (scene_lds_bytes > kLdsSceneBytes || sc.n_tris >= 4095u || bvh_depth > 200) return false;
+    if (fp.bounce_limit > 60000) return false;                                            // the bounce index is kept in 16 bits
     if (sc.root_ref == kNoNode) return false;
     return true;
 }
@@ -538,21 +605,40 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     const uint64_t n_chunks = (uint64_t)tiles_x * tiles_y * fp.n_frames;
     if (n_chunks * 64ull > 0xFFF00000ull) return hipErrorInvalidValue;
     const uint32_t stack_entries = (uint32_t)std::max(bvh_depth, 1);
-    const uint32_t scene_bytes = sc.n_inner * 64u + sc.n_tris * 48u + ((sc.n_leaves * 8u + 15u) & ~15u);
-    int threads = env_threads > 0 ? std::min(env_threads, kMaxPoolThreads) / 64 * 64 : 512;
-    threads = std::max(threads, 64);
-    // the pool: as many paths as the CU's LDS holds next to the scene copy, at most 1024, at least twice the lanes
-    uint32_t P = env_paths > 0 ? (uint32_t)env_paths / 64u * 64u : 1024u;
-    P = std::max<uint32_t>(64u, std::min<uint32_t>(P, 4032u));
-    uint32_t ring_cap = 64;
-    for (;;) {
-        ring_cap = 64;
-        while (ring_cap < P) ring_cap *= 2;
-        if (pool_layout(P, ring_cap, stack_entries, scene_bytes).total <= 160u * 1024u || P <= 64u) break;
-        P -= 64u;
+    const uint32_t scene_bytes = pool_scene_bytes(sc);
+    // the shading records go to LDS too when they are small (cornell: 1.2 KB): B's load chain triangle -> material ->
+    // texture header then runs through LDS instead of three dependent HBM / L2 round trips
+    const uint32_t cold_bytes = pool_cold_bytes(sc) <= (tune.cold_lds_kb >= 0 ? (uint32_t)tune.cold_lds_kb * 1024u : 4096u) ? pool_cold_bytes(sc) : 0u;
+    // Workgroups per CU, pool size and threads: the most paths the CU's 160 KB of LDS hold (rings are sized to the next power of
+    // two, so 1024 paths per workgroup is a sweet spot), then 4 threads for every 5 paths, at most 24 waves per CU.
+    auto lds_for = [&](uint32_t paths, uint32_t &cap) {
+        cap = 64;
+        while (cap < paths) cap *= 2;
+        return pool_layout(paths, cap, stack_entries, scene_bytes, cold_bytes).total;
+    };
+    uint32_t P = 0, ring_cap = 64;
+    int groups = 1;
+    if (env_paths > 0) {
+        P = std::max<uint32_t>(64u, std::min<uint32_t>((uint32_t)env_paths / 64u * 64u, 4032u));
+        while (P > 64u && lds_for(P, ring_cap) > 160u * 1024u) P -= 64u;
+        (void)lds_for(P, ring_cap);
+    } else {
+        uint32_t best_total = 0;
+        for (int g = 1; g <= 3; g++)
+            for (uint32_t paths = 4032u; paths >= 256u; paths -= 64u) {
+                uint32_t cap;
+                if (lds_for(paths, cap) * (uint32_t)g > 160u * 1024u) continue;
+                if (paths * (uint32_t)g >= best_total) { best_total = paths * (uint32_t)g; P = paths; groups = g; }
+                break;
+            }
+        if (P == 0) return hipErrorInvalidValue;
+        (void)lds_for(P, ring_cap);
     }
-    const PoolLayout lay = pool_layout(P, ring_cap, stack_entries, scene_bytes);
+    const PoolLayout lay = pool_layout(P, ring_cap, stack_entries, scene_bytes, cold_bytes);
     if (lay.total > 160u * 1024u) return hipErrorInvalidValue;
+    int threads;
+    if (env_threads > 0) threads = std::max(64, std::min(env_threads, kMaxPoolThreads) / 64 * 64);
+    else threads = std::max(256, std::min<int>({ kMaxPoolThreads, (int)(P * 4u / 5u) / 64 * 64, 1536 / groups / 64 * 64 }));
     auto kernel = tune.stats ? path_pool_kernel<true> : path_pool_kernel<false>;
     if (lay.total > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total);
@@ -566,6 +652,7 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     pp.t_class[0] = t_class[0]; pp.t_class[1] = t_class[1]; pp.t_class[2] = t_class[2];
     pp.min_fill = (uint32_t)std::max(1, std::min(env_fill, 64)); pp.patience = (uint32_t)std::max(0, env_patience);
     pp.n_loop = (uint32_t)std::max(1, tune.n_loop); pp.n_min_lanes = (uint32_t)std::max(1, std::min(tune.n_min_lanes, 64));
+    pp.cold_in_lds = cold_bytes > 0 ? 1u : 0u;
     pp.status = status; pp.stats = tune.stats;
     // one pool fills with P samples at once: never more workgroups than that leaves work for
     const uint64_t want = std::min<uint64_t>((uint64_t)num_cus * per_cu, std::max<uint64_t>(1, (n_chunks * 64ull + P - 1) / P));
