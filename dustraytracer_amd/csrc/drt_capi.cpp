@@ -100,7 +100,7 @@ struct drt_renderer {
     int num_cus = 256;
     int frames_in_flight = 1;                 // drt_renderer_set_frames_in_flight
     bool use_pixel_walk = false;              // DRT_KERNEL=pixel_walk selects the first (non-persistent) kernel
-    int use_path_pool = 0;                    // DRT_KERNEL=path_pool / wave_queue: 1 = path_pool where it applies, 0 = never
+    int use_path_pool = 1;                    // path_pool where it applies (lean paths, scene in LDS); DRT_KERNEL=wave_queue: never
     unsigned int *pool_status = nullptr;      // device word: set by an aborted path_pool launch
     PoolScratch pool_scratch;
     PoolTuning pool_tuning;                   // DRT_POOL_THREADS / _PATHS / _MIN_FILL / _PATIENCE
@@ -308,7 +308,7 @@ drt_renderer *drt_renderer_create(int32_t device) {
     drt_default_settings(&r->settings);
     const char *which = std::getenv("DRT_KERNEL");
     r->use_pixel_walk = which && std::strcmp(which, "pixel_walk") == 0;
-    r->use_path_pool = which && std::strcmp(which, "path_pool") == 0;
+    r->use_path_pool = !(which && (std::strcmp(which, "wave_queue") == 0 || std::strcmp(which, "pixel_walk") == 0));
     auto env_int = [](const char *name, int dflt) { const char *v = std::getenv(name); return (v && *v) ? std::atoi(v) : dflt; };
     r->vote_node = std::max(1, env_int("DRT_VOTE_N", r->vote_node));
     r->vote_shade = std::max(1, env_int("DRT_VOTE_S", r->vote_shade));
@@ -324,6 +324,7 @@ drt_renderer *drt_renderer_create(int32_t device) {
     r->pool_tuning.n_loop = env_int("DRT_POOL_N_LOOP", r->pool_tuning.n_loop);
     r->pool_tuning.n_min_lanes = env_int("DRT_POOL_N_MIN", r->pool_tuning.n_min_lanes);
     r->pool_tuning.cold_lds_kb = env_int("DRT_POOL_COLD_KB", r->pool_tuning.cold_lds_kb);
+    r->pool_tuning.share_grid = env_int("DRT_POOL_SHARE_GRID", r->pool_tuning.share_grid);
     if (env_int("DRT_POOL_STATS", 0) != 0 && hipMalloc((void **)&r->pool_tuning.stats, 32 * sizeof(unsigned long long)) == hipSuccess)
         (void)hipMemset(r->pool_tuning.stats, 0, 32 * sizeof(unsigned long long));
     int cus = 0;

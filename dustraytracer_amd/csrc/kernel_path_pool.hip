@@ -654,8 +654,12 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     pp.n_loop = (uint32_t)std::max(1, tune.n_loop); pp.n_min_lanes = (uint32_t)std::max(1, std::min(tune.n_min_lanes, 64));
     pp.cold_in_lds = cold_bytes > 0 ? 1u : 0u;
     pp.status = status; pp.stats = tune.stats;
-    // one pool fills with P samples at once: never more workgroups than that leaves work for
-    const uint64_t want = std::min<uint64_t>((uint64_t)num_cus * per_cu, std::max<uint64_t>(1, (n_chunks * 64ull + P - 1) / P));
+    // one pool fills with P samples at once: never more workgroups than that leaves work for.  When the caller keeps several
+    // launches in flight (drt_renderer_set_frames_in_flight) each gets its share of the workgroup slots, so that they run side
+    // by side and the ramp-up and drain of one overlap the steady state of the others instead of queueing behind a full grid.
+    uint64_t want = std::min<uint64_t>((uint64_t)num_cus * per_cu, std::max<uint64_t>(1, (n_chunks * 64ull + P - 1) / P));
+    if (fp.frames_in_flight > 1 && tune.share_grid)
+        want = std::min<uint64_t>(want, std::max<uint64_t>(1, ((uint64_t)num_cus * per_cu + fp.frames_in_flight - 1) / (uint64_t)fp.frames_in_flight));
     // the part of the path state that lives in HBM: 20 bytes per pool slot of every workgroup
     const size_t slots = (size_t)num_cus * per_cu * P;
     if (slots > scratch.slots) {
