@@ -447,10 +447,10 @@ class Renderer:
         a = np.zeros(32, np.uint64)
         _check(_lib.drt_debug_pool_stats(self._h, a.ctypes.data, 1 if reset else 0))
         out = {}
-        for k, name in enumerate(("N", "T0", "T1", "T2", "T3", "B", "E")):
+        for k, name in enumerate(("N", "T0", "T1", "T2", "T3", "B", "E", "R")):
             b, l, t = int(a[3 * k]), int(a[3 * k + 1]), int(a[3 * k + 2])
             out[name] = (b, l / max(b, 1), t)
-        out["claim_ticks"], out["idle_polls"], out["lost_claims"], out["wave_ticks"] = int(a[21]), int(a[22]), int(a[23]), int(a[24])
+        out["claim_ticks"], out["idle_polls"], out["lost_claims"], out["wave_ticks"] = int(a[24]), int(a[25]), int(a[26]), int(a[27])
         return out
 
     def kernelSpanMs(self):

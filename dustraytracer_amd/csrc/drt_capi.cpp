@@ -325,6 +325,7 @@ drt_renderer *drt_renderer_create(int32_t device) {
     r->pool_tuning.n_min_lanes = env_int("DRT_POOL_N_MIN", r->pool_tuning.n_min_lanes);
     r->pool_tuning.cold_lds_kb = env_int("DRT_POOL_COLD_KB", r->pool_tuning.cold_lds_kb);
     r->pool_tuning.share_grid = env_int("DRT_POOL_SHARE_GRID", r->pool_tuning.share_grid);
+    r->pool_tuning.dir_tries = env_int("DRT_POOL_DIR_TRIES", r->pool_tuning.dir_tries);
     if (env_int("DRT_POOL_STATS", 0) != 0 && hipMalloc((void **)&r->pool_tuning.stats, 32 * sizeof(unsigned long long)) == hipSuccess)
         (void)hipMemset(r->pool_tuning.stats, 0, 32 * sizeof(unsigned long long));
     int cus = 0;

@@ -9,7 +9,8 @@
 //     N      pop one entry of its traversal stack; interior node: slab-test both children, push     BVHTraversal.cuh:33-72
 //     T0..T3 test the triangles of the leaf it stands on, two per step (one queue per leaf-size class,
 //            so that the lanes of a batch run the same number of steps)                             BVHTraversal.cuh:46-57
-//     B      shade the closest hit, draw the bounce direction, launch the bounce ray                 RayGen.cuh:90-134
+//     B      shade the closest hit, draw the bounce direction (a few candidates), launch the bounce ray  RayGen.cuh:90-134
+//     R      more candidates for the paths whose direction was still rejected, then launch             Random.cu:50-58
 //     E      finish the path (sky term, tone map, gamma, store the sample), take a new sample,
 //            generate its primary ray                                                               RayGen.cuh:63-108,165-171
 // A wave claims up to 64 path ids of ONE queue, loads the part of the state that phase needs, runs the phase with every
@@ -38,8 +39,8 @@ namespace drt {
 
 namespace {
 
-constexpr int kNQ = 7;                               // queues: N, T0..T3, B, E
-enum : int { QN = 0, QT0 = 1, QB = 5, QE = 6 };
+constexpr int kNQ = 8;                               // queues: N, T0..T3, B, E, R
+enum : int { QN = 0, QT0 = 1, QB = 5, QE = 6, QR = 7 };
 constexpr uint32_t kEmptyId = 0xFFFFu;
 constexpr uint32_t kNoPrim = 0xFFFu;                 // word W: hit triangle (12 bits, kNoPrim = none) | bounce index << 12 (16 bits) | kHasSample
 constexpr uint32_t kHasSample = 1u << 28;
@@ -134,6 +135,7 @@ struct PoolParams {
     uint32_t n_loop;           // N: at most this many pops per batch ...
     uint32_t n_min_lanes;      // ... and the batch ends when fewer lanes than this are still popping (the rest go back to N)
     uint32_t cold_in_lds;      // TriCold / MatDev / TexDev records staged in LDS too (small scenes): B's loads chain through LDS
+    uint32_t dir_tries;        // B and R draw at most this many candidates of the bounce direction per batch; paths still without one go (back) to R
     uint4 *aux;                // HBM, [workgroup][path]: {throughput, seed} -- what only B and E touch stays out of LDS
     uint32_t *aux_slot;        // HBM, [workgroup][path]: where the path's sample goes in `samples`
     unsigned int *status;      // device word: != 0 after an aborted launch
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         // ---------------- choose a queue and claim up to 64 of its ids ----------------
         // Queues holding a full batch are shared out round robin (the waves of a workgroup would otherwise all race for
         // the same one); with none, the fullest queue is taken -- after a short wait for company unless the launch is draining.
-        // One LDS read fetches every control word: lanes 0..6 their queue's {head, tail}, lane 8 {live, abort}, lane 9 {exhausted}.
+        // One LDS read fetches every control word: lanes 0..7 their queue's {head, tail}, lane 8 {live, abort}, lane 9 {exhausted}.
         uint2 my_ctrl = make_uint2(0u, 0u);
         if (lane < 10) my_ctrl = ld2_shared(ctrl + (uint32_t)lane * 8u);
         const int my_avail = lane < kNQ ? (int)(my_ctrl.y - my_ctrl.x) : 0;
@@ -385,6 +387,36 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         unsigned long long s_t1 = 0;
         if (STATS) { s_t1 = __builtin_amdgcn_s_memtime(); s_claim += s_t1 - s_t0; s_batches[q]++; s_lanes[q] += n; }
         int dest = -1;                                                    // queue this lane's path goes to next
+        // bounce direction being drawn (B, R): randomUnitSphereVec3 is a rejection loop (Random.cu:50-58, ~2.9 candidates on
+        // average, a long tail); a batch draws at most pp.dir_tries candidates per path with every lane that still needs one,
+        // then launches the rays that have their direction and sends the others to R with their RNG state
+        bool need_dir = false;
+        f3 dir_origin = mk3(0, 0, 0), dir_normal = mk3(0, 0, 0), dir_thr = mk3(1, 1, 1);
+        uint32_t dir_seed = 0, dir_bounce = 0, dir_tries = 0;
+        auto draw_and_launch = [&](bool store_throughput) {
+            f3 p = mk3(0, 0, 0);
+            bool have = false;
+            for (uint32_t k = 0; k < pp.dir_tries; k++) {
+                const bool go = need_dir && !have;
+                if (pp_ballot(go) == 0) break;
+                // (the cycle guard of device_math.hpp: the kMaxTries-th candidate is taken whatever it is)
+                if (go) { have = random_unit_sphere_try(dir_seed, p) || ++dir_tries >= (uint32_t)kMaxTries; }
+            }
+            if (need_dir) {
+                if (have) {
+                    // the RNG state goes on with the path (:91 of the next bounce reads it); B also has a new throughput
+                    if (store_throughput) aux[id] = make_uint4(f2u(dir_thr.x), f2u(dir_thr.y), f2u(dir_thr.z), dir_seed);
+                    else reinterpret_cast<uint32_t *>(aux + id)[3] = dir_seed;
+                    dest = launch_ray(id, make_ray(dir_origin, dir_normal + p), dir_bounce, true);          // :134
+                } else {
+                    if (store_throughput) aux[id] = make_uint4(f2u(dir_thr.x), f2u(dir_thr.y), f2u(dir_thr.z), dir_seed);
+                    st4(qA + id * 16u, make_uint4(f2u(dir_origin.x), f2u(dir_origin.y), f2u(dir_origin.z), dir_seed));
+                    st4(qB + id * 16u, make_uint4(f2u(dir_normal.x), f2u(dir_normal.y), f2u(dir_normal.z), dir_tries));
+                    st1(qW + id * 4u, kNoPrim | (dir_bounce << 12) | kHasSample);
+                    dest = QR;
+                }
+            }
+        };
 
         if (q == QN) {
             // ============ N: pop stack entries until the path stands on a leaf (BVHTraversal.cuh:33-72) ============
@@ -454,6 +486,16 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 if (dest < 0) { packed = (uint32_t)sp << 24; dest = sp > 0 ? QN : after_traversal(hit_t); }
                 st1(qB + id * 16u + 12u, packed);
             }
+        } else if (q == QR) {
+            // ============ R: more candidates for directions B could not settle (Random.cu:50-58), then the launch ============
+            if (active) {
+                const uint4 A = ld4(qA + id * 16u), B = ld4(qB + id * 16u);
+                need_dir = true;
+                dir_origin = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); dir_seed = A.w;
+                dir_normal = mk3(u2f(B.x), u2f(B.y), u2f(B.z)); dir_tries = B.w;
+                dir_bounce = (ld1(qW + id * 4u) >> 12) & 0xFFFFu;
+            }
+            draw_and_launch(false);
         } else if (q == QB) {
             // ============ B: shade the hit, draw the bounce direction, launch the bounce ray (RayGen.cuh:90-134) ============
             if (active) {
@@ -480,14 +522,14 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 const f3 origin = position + (normal * 0.001f);                            // :121
                 ++bounce;
                 if ((int)bounce <= fp.bounce_limit) {                                      // :88 loop condition
-                    const f3 p = random_unit_sphere_vec3_try(seed);                        // :133 (Random.cu:50-58)
-                    aux[id] = make_uint4(f2u(throughput.x), f2u(throughput.y), f2u(throughput.z), seed);
-                    dest = launch_ray(id, make_ray(origin, normal + p), bounce, true);     // :134
+                    need_dir = true; dir_origin = origin; dir_normal = normal; dir_seed = seed; dir_bounce = bounce; dir_tries = 0;
+                    dir_thr = throughput;
                 } else {
                     st1(qA + id * 16u + 12u, 0u);        // the path ends without reaching the sky: E adds no light (hit_t != FLT_MAX)
                     dest = QE;
                 }
             }
+            draw_and_launch(true);
         } else {
             // ============ E: finish the path, store its sample; deal a new sample, primary ray (RayGen.cuh:63-108,165-171) ============
             if (active) {
@@ -610,7 +652,7 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     // texture header then runs through LDS instead of three dependent HBM / L2 round trips
     const uint32_t cold_bytes = pool_cold_bytes(sc) <= (tune.cold_lds_kb >= 0 ? (uint32_t)tune.cold_lds_kb * 1024u : 4096u) ? pool_cold_bytes(sc) : 0u;
     // Workgroups per CU, pool size and threads: the most paths the CU's 160 KB of LDS hold (rings are sized to the next power of
-    // two, so 1024 paths per workgroup is a sweet spot), then 4 threads for every 5 paths, at most 24 waves per CU.
+    // two, so 1024 paths per workgroup is a sweet spot), then as many threads as paths, at most 24 waves per CU (16 in one workgroup).
     auto lds_for = [&](uint32_t paths, uint32_t &cap) {
         cap = 64;
         while (cap < paths) cap *= 2;
@@ -638,7 +680,7 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     if (lay.total > 160u * 1024u) return hipErrorInvalidValue;
     int threads;
     if (env_threads > 0) threads = std::max(64, std::min(env_threads, kMaxPoolThreads) / 64 * 64);
-    else threads = std::max(256, std::min<int>({ kMaxPoolThreads, (int)(P * 4u / 5u) / 64 * 64, 1536 / groups / 64 * 64 }));
+    else threads = std::max(256, std::min<int>({ kMaxPoolThreads, (int)P / 64 * 64, 1536 / groups / 64 * 64 }));
     auto kernel = tune.stats ? path_pool_kernel<true> : path_pool_kernel<false>;
     if (lay.total > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total);
@@ -653,6 +695,7 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     pp.min_fill = (uint32_t)std::max(1, std::min(env_fill, 64)); pp.patience = (uint32_t)std::max(0, env_patience);
     pp.n_loop = (uint32_t)std::max(1, tune.n_loop); pp.n_min_lanes = (uint32_t)std::max(1, std::min(tune.n_min_lanes, 64));
     pp.cold_in_lds = cold_bytes > 0 ? 1u : 0u;
+    pp.dir_tries = (uint32_t)std::max(1, tune.dir_tries);
     pp.status = status; pp.stats = tune.stats;
     // one pool fills with P samples at once: never more workgroups than that leaves work for.  When the caller keeps several
     // launches in flight (drt_renderer_set_frames_in_flight) each gets its share of the workgroup slots, so that they run side

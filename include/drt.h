@@ -222,7 +222,7 @@ int           drt_debug_kat(int32_t device, int32_t which, const void *in, size_
                             const drt_camera *cam, uint32_t width, uint32_t height);
 /* Every 32-bit value on a cycle of the RNG hash (Random.cu:6-11) no longer than max_len: (value, length) pairs. */
 int           drt_debug_hash_cycles(int32_t device, uint32_t max_len, uint32_t *pairs_out, uint32_t cap_pairs, uint32_t *found);
-/* path_pool kernel statistics of a renderer created with DRT_POOL_STATS=1 in the environment: per queue (N, T0..T3, B, E)
+/* path_pool kernel statistics of a renderer created with DRT_POOL_STATS=1 in the environment: per queue (N, T0..T3, B, E, R)
  * {batches, paths served, shader-clock ticks}, then ticks spent claiming, idle polls, lost claims, wave ticks. */
 int           drt_debug_pool_stats(drt_renderer *r, uint64_t out[32], int32_t reset);
 uint32_t      drt_shard_rows(uint32_t height, uint32_t stripe_rows, uint32_t rank, uint32_t world);

@@ -24,7 +24,7 @@ ns = W * H * frames
 print(r.kernelInfo(), "%.3f ms (stats build)" % ms)
 wt = st["wave_ticks"]
 tot_b = 0
-for q in ("N", "T0", "T1", "T2", "T3", "B", "E"):
+for q in ("N", "T0", "T1", "T2", "T3", "B", "E", "R"):
     b_, l_, t_ = st[q]
     tot_b += b_
     print("  %-3s batches/64 samples %6.3f  fill %5.1f  ticks/batch %7.0f  share of wave time %5.1f%%" % (q, b_ / ns * 64, l_, t_ / max(b_, 1), 100.0 * t_ / wt))
