@@ -85,4 +85,13 @@ DRT_DEV Ray camera_get_ray(const FrameParams &fp, f2 uv, uint32_t &seed) {
     return make_ray(rorig, normalize(d));
 }
 
+// ---- RenderKernel.cu:29-34 for one sample of a one-frame launch: accumulation_buffer[p] += c; texel = sum / frame index, alpha 1 ----
+DRT_DEV void accumulate_and_resolve(const FrameParams &fp, uint32_t pixel, f3 c) {
+    float *a = fp.accum + 3 * (size_t)pixel;
+    const f3 acc = ld3(a) + c;
+    a[0] = acc.x; a[1] = acc.y; a[2] = acc.z;
+    const f3 out = acc / (float)fp.frame_first;
+    reinterpret_cast<float4 *>(fp.rgba)[pixel] = make_float4(out.x, out.y, out.z, 1.0f);
+}
+
 }  // namespace drt

@@ -104,6 +104,8 @@ struct FrameParams {
     int32_t vote_tail_node, vote_tail_shade;   // thresholds once the sample queue is empty (drain of the launch)
     int32_t leaf_chain;                        // T steps take the next leaf off the stack themselves (shallow trees)
     uint32_t row_step;                         // wave_queue work order: stride over the tile rows, coprime to their number
+    int32_t inline_resolve;                    // the launch holds ONE frame: the tracing kernel adds each sample to the running sum and
+                                               // writes the resolved texel itself (RenderKernel.cu:29-34), no sample buffer, no resolve kernel
 };
 
 }  // namespace drt

@@ -93,7 +93,9 @@ struct drt_renderer {
     int spans_used = 0;
     float span_ms = 0.f;                       // sum of those spans, filled by drt_renderer_wait
     int wall_clock_khz = 100000;
-    unsigned int *tile_counter = nullptr;     // work queue head of the wave_queue kernel
+    static constexpr int kCounters = 256;
+    unsigned int *tile_counter = nullptr;     // work queue heads of the tracing kernels: kCounters zeroed words, one per launch, re-zeroed
+    int counters_used = 0;                    // in one memset when all are spent (no memset in front of every launch)
     void *samples = nullptr;                  // wave_queue: one float4 per (pixel, frame) of a launch
     size_t samples_bytes = 0;
     size_t sample_budget = (size_t)1 << 30;   // frames of one batch are split so that a launch needs at most this much
@@ -335,7 +337,8 @@ drt_renderer *drt_renderer_create(int32_t device) {
     if (hipEventCreate(&r->ev_start) != hipSuccess || hipEventCreate(&r->ev_stop) != hipSuccess ||
         hipMalloc((void **)&r->counters, sizeof(drt_counters)) != hipSuccess ||
         hipMalloc((void **)&r->spans, sizeof(unsigned long long) * 2 * drt_renderer::kMaxSpans) != hipSuccess ||
-        hipMalloc((void **)&r->tile_counter, sizeof(unsigned int)) != hipSuccess ||
+        hipMalloc((void **)&r->tile_counter, sizeof(unsigned int) * drt_renderer::kCounters) != hipSuccess ||
+        hipMemset(r->tile_counter, 0, sizeof(unsigned int) * drt_renderer::kCounters) != hipSuccess ||
         hipMalloc((void **)&r->pool_status, sizeof(unsigned int)) != hipSuccess ||
         hipMemset(r->pool_status, 0, sizeof(unsigned int)) != hipSuccess) {
         fail(DRT_ERR_DEVICE, "cannot create HIP events / counter buffer");
@@ -406,6 +409,11 @@ int drt_renderer_bind_buffers(drt_renderer *r, void *device_accum, void *device_
 
 int drt_renderer_set_stream(drt_renderer *r, void *hip_stream) {
     if (!r) return fail(DRT_ERR_INVALID, "null renderer");
+    if (r->stream != (hipStream_t)hip_stream) {
+        // launches still running on the old stream own queue-head counters that the new stream's bulk re-zero must not touch
+        HIP_TRY(hipSetDevice(r->device));
+        HIP_TRY(hipStreamSynchronize(r->stream));
+    }
     r->stream = (hipStream_t)hip_stream;
     return DRT_OK;
 }
@@ -619,12 +627,17 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
             fp.frame_first = r->frame_index + done;
             fp.n_frames = std::min(frames_per_launch, n_frames - done);
             fp.span = r->spans_used < drt_renderer::kMaxSpans ? r->spans + 2 * r->spans_used++ : nullptr;
+            if (r->counters_used == drt_renderer::kCounters) {      // stream order: every launch that used them is over by then
+                HIP_TRY(hipMemsetAsync(r->tile_counter, 0, sizeof(unsigned int) * drt_renderer::kCounters, r->stream));
+                r->counters_used = 0;
+            }
+            unsigned int *const queue_head = r->tile_counter + r->counters_used++;
             if (r->use_path_pool && !r->counting &&
                 path_pool_supports(r->view, fp, r->bvh_depth, r->scene_has_alpha, wave_queue_scene_lds_bytes(r->view)))
-                HIP_TRY(launch_path_pool(r->view, fp, r->bvh_depth, r->pool_t_class, r->pool_tuning, r->pool_scratch, r->tile_counter, r->samples, r->pool_status,
+                HIP_TRY(launch_path_pool(r->view, fp, r->bvh_depth, r->pool_t_class, r->pool_tuning, r->pool_scratch, queue_head, r->samples, r->pool_status,
                                          r->num_cus, r->stream, &r->kernel_name, r->launch_shape));
             else
-            HIP_TRY(launch_wave_queue(r->view, fp, r->bvh_depth, r->counting ? 2 : 0, r->scene_has_alpha, r->tile_counter,
+            HIP_TRY(launch_wave_queue(r->view, fp, r->bvh_depth, r->counting ? 2 : 0, r->scene_has_alpha, queue_head,
                                       r->samples, r->num_cus, r->stream, &r->kernel_name, r->launch_shape));
         }
     }

@@ -543,7 +543,8 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                         light = light + sky_model(mk3(u2f(B.x), u2f(B.y), u2f(B.z)), ld3(fp.sky_color)) * mk3(u2f(E.x), u2f(E.y), u2f(E.z)) * fp.sky_intensity;
                     if (fp.tone_mapping) light = uncharted2_filmic(light, fp.exposure);    // :165-169 (wave-uniform branches)
                     if (fp.gamma_correction) light = gamma_correction(light);
-                    samples[slot] = make_float4(light.x, light.y, light.z, 0.0f);
+                    if (fp.inline_resolve) accumulate_and_resolve(fp, slot, light);        // one frame in the launch: slot = pixel
+                    else samples[slot] = make_float4(light.x, light.y, light.z, 0.0f);
                 }
             }
             // one global atomic per batch hands out the sample ids
@@ -716,13 +717,14 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
         scratch.slots = slots;
     }
     pp.aux = static_cast<uint4 *>(scratch.aux); pp.aux_slot = static_cast<uint32_t *>(scratch.aux_slot);
-    hipError_t e = hipMemsetAsync(sample_counter, 0, sizeof(unsigned int), stream);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;                 // (*sample_counter is zero: drt_capi.cpp hands out zeroed counters)
     if (kernel_name) *kernel_name = "path_pool<lean,lds-scene>";
     if (launch_shape) { launch_shape[0] = (int)stack_entries; launch_shape[1] = per_cu; launch_shape[2] = (int)(lay.total / 1024); launch_shape[3] = threads; launch_shape[4] = (int)P; }
-    hipLaunchKernelGGL(kernel, dim3((unsigned)want), dim3(threads), lay.total, stream, sc, fp, pp, sample_counter, static_cast<float4 *>(samples));
+    FrameParams fq = fp;
+    fq.inline_resolve = fp.n_frames == 1 ? 1 : 0;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)want), dim3(threads), lay.total, stream, sc, fq, pp, sample_counter, static_cast<float4 *>(samples));
     e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || fq.inline_resolve) return e;
     return launch_resolve(fp, samples, stream);
 }
 

@@ -849,14 +849,15 @@ hipError_t launch_wave_queue(const SceneView &sc, const FrameParams &fp, int bvh
     const size_t scene_bytes = wave_queue_scene_lds_bytes(sc);
     static const size_t lds_scene_budget = std::getenv("DRT_LDS_SCENE_KB") ? (size_t)std::atoi(std::getenv("DRT_LDS_SCENE_KB")) * 1024 : kLdsSceneBytes;
     const bool lds_scene = scene_bytes <= lds_scene_budget;
-    hipError_t e = hipMemsetAsync(chunk_counter, 0, sizeof(unsigned int), stream);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;                 // (*chunk_counter is zero: drt_capi.cpp hands out zeroed counters)
     static const char *names[2][6] = { { "wave_queue<lean,hbm-scene>", "wave_queue<general,hbm-scene>", "wave_queue<counting,hbm-scene>", "wave_queue<lean+alpha,hbm-scene>",
                                          "wave_queue<lean+sun,hbm-scene>", "wave_queue<lean+alpha+sun,hbm-scene>" },
                                        { "wave_queue<lean,lds-scene>", "wave_queue<general,lds-scene>", "wave_queue<counting,lds-scene>", "wave_queue<lean+alpha,lds-scene>",
                                          "wave_queue<lean+sun,lds-scene>", "wave_queue<lean+alpha+sun,lds-scene>" } };
     if (kernel_name) *kernel_name = names[lds_scene ? 1 : 0][mode];
     float4 *s4 = static_cast<float4 *>(samples);
+    // (the one-frame shortcut of path_pool -- accumulate and resolve inside the tracing kernel -- costs this kernel a register
+    // too many: its 6-byte-stack variants go from 80 to 81 VGPRs = 6 -> 5 waves per SIMD)
     e = launch_mode(sc, fp, mode, lds_scene, chunk_counter, s4, (uint32_t)stack, lds_scene ? scene_bytes : 0, num_cus, stream, launch_shape);
     if (e != hipSuccess) return e;
     return launch_resolve(fp, samples, stream);

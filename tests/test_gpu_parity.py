@@ -573,8 +573,8 @@ def test_bench_two_rank_rehearsal_assembles_the_single_device_image():
 def test_kernel_packaging_follows_the_scene_and_the_view():
     """launch_one picks workgroup size, stack entry size and triangles per T step per scene and view (DESIGN.md 4 / 5.1);
     whatever it picks, the image is the oracle's.  The choices themselves are pinned here so that a change shows up."""
-    expect = {"cornell_box": "wave_queue<lean,lds-scene> stack=3 wg/CU=6 ",            # small LDS scene: 256 threads, 6 groups
-              "room": "x512",                                                          # 17.6 KB LDS scene: 512-thread groups
+    expect = {"cornell_box": "path_pool<lean,lds-scene> stack=3 wg/CU=2 ",             # small LDS scene, lean paths: the path pool, two pools per CU
+              "room": "path_pool<lean,lds-scene> stack=8 wg/CU=1 ",                    # 17.6 KB LDS scene, 8-level tree: one pool per CU
               "cs16_dust": "stack=16x6B wg/CU=6",                                      # deep tree from HBM, camera inside: 6-byte entries
               "suzanne_plane": "tris=3"}                                               # tree from HBM, camera outside: three triangles per step
     r = drt.Renderer(0)
@@ -590,3 +590,46 @@ def test_kernel_packaging_follows_the_scene_and_the_view():
         assert marker in r.kernelInfo(), (name, r.kernelInfo())
         ref, _, _ = oracle.render(osc, ocam, o, W, H, 1, 2)
         compare(r.GetRenderTargetImage(), ref, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["path_pool", "wave_queue"])
+@pytest.mark.parametrize("name,W,H,frames,depth", [("cornell_box", 160, 90, 3, 8), ("room", 128, 72, 2, 16), ("bvh_split_test", 96, 64, 2, 4),
+                                                    ("cornell_box", 61, 37, 2, 0), ("room", 64, 64, 1, 32)])
+def test_both_tracing_kernels_match_the_oracle_on_lds_scenes(kernel, name, W, H, frames, depth):
+    """Scenes whose traversal data fits LDS are traced by path_pool (kernel_path_pool.hip: path state parked in LDS,
+    phase-homogeneous batches) unless DRT_KERNEL=wave_queue; both are bit-exact, partial tiles and long paths included."""
+    r, ref, ref_acc = _render_with_env({"DRT_KERNEL": kernel}, name, W, H, frames, depth)
+    assert r.kernelInfo().startswith(kernel), r.kernelInfo()
+    compare(r.GetRenderTargetImage(), ref, "%s %s" % (kernel, name))
+    compare(r.GetAccumulationBuffer(), ref_acc, "%s %s accum" % (kernel, name))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"DRT_POOL_THREADS": "64", "DRT_POOL_PATHS": "64"}, {"DRT_POOL_THREADS": "1024", "DRT_POOL_PATHS": "256"},
+                                 {"DRT_POOL_MIN_FILL": "1", "DRT_POOL_PATIENCE": "0", "DRT_POOL_N_LOOP": "1"},
+                                 {"DRT_POOL_MIN_FILL": "64", "DRT_POOL_PATIENCE": "100", "DRT_POOL_DIR_TRIES": "1", "DRT_POOL_N_LOOP": "64", "DRT_POOL_N_MIN": "1"},
+                                 {"DRT_POOL_DIR_TRIES": "2000", "DRT_POOL_COLD_KB": "0"}, {"DRT_POOL_PATHS": "4032", "DRT_POOL_COLD_KB": "64"}])
+def test_path_pool_scheduling_knobs_do_not_change_the_image(env):
+    """Pool size, workgroup size, batch thresholds, candidates per batch: scheduling only (the RNG state is a pure function of
+    pixel, frame and draw count), so every setting gives the oracle's bits."""
+    r, ref, _ = _render_with_env(dict(env, DRT_KERNEL="path_pool"), "room", 96, 54, 2, 6)
+    assert r.kernelInfo().startswith("path_pool"), r.kernelInfo()
+    compare(r.GetRenderTargetImage(), ref, "pool knobs %r" % (env,))
+
+
+@pytest.mark.gpu
+def test_path_pool_falls_back_where_it_does_not_apply():
+    """Sunlight, debug views, alpha textures, scenes too big for LDS and the counting build stay on wave_queue."""
+    for name, kw in (("cornell_box", dict(enableSunlight=1)), ("cornell_box", dict(RenderMode=1, DebugMode=1)), ("uv_texture_test", {}),
+                     ("suzanne_plane", {})):
+        sc, osc = make_pair(name)
+        cam, ocam = cameras(name)
+        s, o = settings_pair(ray_bounce_limit=3, **kw)
+        r = drt.Renderer(0)
+        r.m_RendererSettings = s
+        r.ResizeBuffer(96, 54)
+        r.RenderBatch(cam, sc, 2)
+        assert r.kernelInfo().startswith("wave_queue"), (name, kw, r.kernelInfo())
+        ref, _, _ = oracle.render(osc, ocam, o, 96, 54, 1, 2)
+        compare(r.GetRenderTargetImage(), ref, "%s %r" % (name, kw))
