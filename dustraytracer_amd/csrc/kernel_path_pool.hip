@@ -20,8 +20,9 @@
 // same device_math.hpp code as wave_queue's, so the image is bit-identical; only who computes what when differs.
 //
 // Queues are rings of 16-bit path ids in LDS, multi-producer / multi-consumer inside the workgroup: a producer reserves a
-// position with an atomic add on the tail and writes the id there; a consumer claims [head, head+n) with one
-// compare-and-swap on the head and reads the ids (an entry still 0xFFFF = reserved but not written yet: re-read).
+// position with an atomic add on the tail and writes the id there once the slot is empty (0xFFFF); a consumer claims
+// [head, head+n) with one compare-and-swap on the head, reads the ids (an entry still 0xFFFF = reserved but not written
+// yet: re-read) and empties the slots.  Every wait is on a strictly older ring position, so there is no cycle.
 // Every wait in this kernel is bounded: a wave that polls too long raises the abort flag, all waves leave, the host
 // reports DRT_ERR_DEVICE (status word) -- a logic error must never hang the GPU.
 // No MFMA (branchy scalar fp32 / u32).  Citations are relative to /root/reference/DustRayTracer/src/.
@@ -281,7 +282,16 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         uint32_t base = 0;
         if (dest >= 0 && lane == my_leader) base = lds_add(ctrl + (uint32_t)dest * 8u + 4u, add_count);
         base = (uint32_t)__builtin_amdgcn_ds_bpermute(my_leader << 2, (int)base);
-        if (dest >= 0) st_id(rings + ((uint32_t)dest * pp.ring_cap + ((base + my_rank) & ring_mask)) * 2u, id);
+        if (dest >= 0) {
+            // The slot may still hold the id of the previous lap: its consumer has claimed it (at most P <= ring_cap ids are ever
+            // outstanding, so the head is past it) but may not have read and cleared it yet -- at the start, when E's ring holds
+            // all P ids, a path that goes straight back to E lands on exactly such a slot.  Wait for the slot to be empty.
+            const uint32_t at = rings + ((uint32_t)dest * pp.ring_cap + ((base + my_rank) & ring_mask)) * 2u;
+            uint32_t spins = 0;
+            while (ld_id(at) != kEmptyId)
+                if (++spins > (1u << 24)) { st1_shared(ctrl + kCtrlAbort, 3u); if (pp.status) atomicOr(pp.status, 4u); break; }
+            st_id(at, id);
+        }
     };
     const f3 root_min = ld3(sc.root_min), root_max = ld3(sc.root_max);
     // TraceRay.cu:15-20 + BVHTraversal.cuh:22-26,38: the root goes on the stack with its slab distance when -1 < d < FLT_MAX
@@ -547,13 +557,18 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                     else samples[slot] = make_float4(light.x, light.y, light.z, 0.0f);
                 }
             }
-            // one global atomic per batch hands out the sample ids
-            const unsigned long long m = pp_ballot(active);
+            // Sample ids.  The first P of a workgroup are fixed (workgroup w starts with [w*P, (w+1)*P): the slots that wait in E's
+            // ring when the kernel starts, positions < P) -- no 8 000 waves hammering one counter while the launch ramps up; after
+            // that one global atomic per batch hands out the ids above gridDim.x * P.
+            const bool initial = active && head + (uint32_t)lane < P;
+            const unsigned long long m = pp_ballot(active && !initial);
             unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(sample_counter, (unsigned int)__popcll(m));
-            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+            if (m != 0) {
+                if (lane == 0) base = atomicAdd(sample_counter, (unsigned int)__popcll(m));
+                base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base) + gridDim.x * P;
+            }
             if (active) {
-                const uint32_t sid = base + (uint32_t)pp_rank(m);
+                const uint32_t sid = initial ? blockIdx.x * P + head + (uint32_t)lane : base + (uint32_t)pp_rank(m);
                 if (sid >= pp.total_samples) {
                     st1_shared(ctrl + kCtrlExhausted, 1u);
                     lds_add(ctrl + kCtrlLive, 0xFFFFFFFFu);                                // this pool slot retires
