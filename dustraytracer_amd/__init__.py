@@ -187,6 +187,7 @@ _sig("drt_scene_set_geometry", C.c_int, _P, _P, _P, _P, _P, C.c_int32)
 _sig("drt_scene_add_material", C.c_int, _P, C.POINTER(C.c_float), C.c_int32)
 _sig("drt_scene_add_texture", C.c_int, _P, _P, C.c_int32, C.c_int32, C.c_int32)
 _sig("drt_scene_build_bvh", C.c_int, _P, C.c_int32, C.c_int32)
+_sig("drt_scene_validate", C.c_int, _P)
 _sig("drt_scene_build_bvh_device", C.c_int, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float))
 for _n in ("triangle", "node", "material", "texture", "mesh"):
     _sig("drt_scene_%s_count" % _n, C.c_int32, _P)
@@ -277,8 +278,14 @@ class Scene:
         pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 9)
         nrm = np.ascontiguousarray(normals, np.float32).reshape(-1, 9)
         uv = np.ascontiguousarray(uvs, np.float32).reshape(-1, 6)
-        mat = np.ascontiguousarray(material_ids, np.int32)
+        mat = np.ascontiguousarray(material_ids, np.int32).reshape(-1)
+        if not (len(pos) == len(nrm) == len(uv) == len(mat)):
+            raise ValueError("setGeometry: %d position, %d normal, %d uv triangles for %d material ids" % (len(pos), len(nrm), len(uv), len(mat)))
         _check(_lib.drt_scene_set_geometry(self._h, pos.ctypes.data, nrm.ctypes.data, uv.ctypes.data, mat.ctypes.data, len(mat)))
+
+    def validate(self):
+        """Raises DrtError(ERR_INVALID) if a triangle names a material, or a material a texture, that does not exist."""
+        _check(_lib.drt_scene_validate(self._h))
 
     def addMaterial(self, albedo, albedo_tex=-1):
         a = (C.c_float * 3)(*albedo)

@@ -239,6 +239,11 @@ int drt_scene_build_bvh_device(drt_scene *s, int32_t target_leaf_prims, int32_t 
     } catch (...) { return from_exception(); }
 }
 
+int drt_scene_validate(const drt_scene *s) {
+    if (!s) return fail(DRT_ERR_INVALID, "null scene");
+    try { (void)s->host.pack(); return DRT_OK; } catch (...) { return from_exception(); }
+}
+
 int32_t drt_scene_triangle_count(const drt_scene *s) { return s ? (int32_t)s->host.triangles.size() : 0; }
 int32_t drt_scene_node_count(const drt_scene *s) { return s ? (int32_t)s->host.nodes.size() : 0; }
 int32_t drt_scene_material_count(const drt_scene *s) { return s ? (int32_t)s->host.materials.size() : 0; }

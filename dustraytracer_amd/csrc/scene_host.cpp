@@ -166,11 +166,16 @@ Accessor open_accessor(const JsonValue &root, const std::vector<std::pair<const 
                        : acc.component == 5121 || acc.component == 5120 ? 1 : 0;
     if (!csize) throw std::runtime_error("unknown accessor componentType");
     acc.normalized = a.at("normalized").kind == JsonValue::Bool && a.at("normalized").b;
-    acc.count = (size_t)a.at("count").as_int(0);
+    // Every number comes from the file: negative values must not turn into huge size_t's, and the range check must not wrap.
+    const int64_t count = a.at("count").as_int(0), byte_offset = a.at("byteOffset").as_int(0);
     const BufferView &v = views[(size_t)bv];
-    acc.stride = v.stride > 0 ? (size_t)v.stride : csize * (size_t)acc.width;
-    const size_t offset = (size_t)a.at("byteOffset").as_int(0);
-    if (acc.count && offset + acc.stride * (acc.count - 1) + csize * (size_t)acc.width > (size_t)v.length)
+    if (count < 0 || byte_offset < 0 || v.stride < 0) throw std::runtime_error("accessor with a negative count, byteOffset or byteStride");
+    acc.count = (size_t)count;
+    const size_t elem = csize * (size_t)acc.width;
+    acc.stride = v.stride > 0 ? (size_t)v.stride : elem;
+    const size_t offset = (size_t)byte_offset, length = (size_t)v.length;
+    // last element ends at offset + stride*(count-1) + elem <= length, written without a product that can overflow
+    if (acc.count && (offset > length || elem > length - offset || (acc.count - 1) > (length - offset - elem) / acc.stride))
         throw std::runtime_error("accessor runs past its bufferView");
     acc.base = buffers[(size_t)v.buffer].first + v.offset + offset;
     return acc;
@@ -379,8 +384,8 @@ void HostScene::load_gltf(const char *path, bool strict) {
         v.offset = jviews.at(i).at("byteOffset").as_int(0);
         v.length = jviews.at(i).at("byteLength").as_int(0);
         v.stride = jviews.at(i).at("byteStride").as_int(0);
-        if (v.buffer < 0 || (size_t)v.buffer >= buffers.size() || v.offset < 0 || v.length < 0 ||
-            (size_t)(v.offset + v.length) > buffers[(size_t)v.buffer].second)
+        if (v.buffer < 0 || (size_t)v.buffer >= buffers.size() || v.offset < 0 || v.length < 0 || v.stride < 0 ||
+            (uint64_t)v.offset > buffers[(size_t)v.buffer].second || (uint64_t)v.length > buffers[(size_t)v.buffer].second - (uint64_t)v.offset)
             throw std::runtime_error("bufferView out of range");
         views.push_back(v);
     }
@@ -735,6 +740,24 @@ PackedScene HostScene::pack() const {
     std::memcpy(ps.root_min, root.bmin, 12);
     std::memcpy(ps.root_max, root.bmax, 12);
 
+    // The kernels index mats[triangle.material], texs[material.albedo_tex] and the texel pool without checks: what the
+    // programmatic API (drt_scene_set_geometry / _add_material) lets through must be refused here, before it is uploaded.
+    for (size_t i = 0; i < n_nodes; i++) {
+        const drt_bvh_node &n = nodes[i];
+        if (n.is_leaf) {
+            if (n.prim_start < 0 || n.prim_count < 0 || (size_t)n.prim_start + (size_t)n.prim_count > triangles.size())
+                throw std::invalid_argument("BVH leaf " + std::to_string(i) + " points outside the triangle array");
+        } else if (n.child1 < 0 || n.child2 < 0 || (size_t)n.child1 >= n_nodes || (size_t)n.child2 >= n_nodes)
+            throw std::invalid_argument("BVH node " + std::to_string(i) + " has a child index outside the node array");
+    }
+    for (size_t i = 0; i < triangles.size(); i++)
+        if (triangles[i].material < 0 || (size_t)triangles[i].material >= materials.size())
+            throw std::invalid_argument("triangle " + std::to_string(i) + " uses material " + std::to_string(triangles[i].material) +
+                                        " but the scene has " + std::to_string(materials.size()) + " materials");
+    for (size_t i = 0; i < materials.size(); i++)
+        if (materials[i].albedo_tex >= (int32_t)textures.size())
+            throw std::invalid_argument("material " + std::to_string(i) + " uses texture " + std::to_string(materials[i].albedo_tex) +
+                                        " but the scene has " + std::to_string(textures.size()) + " textures");
     ps.tri_hot.resize(triangles.size());
     ps.tri_cold.resize(triangles.size());
     for (size_t i = 0; i < triangles.size(); i++) {

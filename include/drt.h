@@ -144,6 +144,9 @@ int        drt_scene_build_bvh(drt_scene *s, int32_t target_leaf_prims, int32_t 
 /* The same build run on GPU `device`: identical nodes, node order and triangle order -- a bound that
  * is a zero may carry the other sign.  build_ms (may be NULL) receives the device time.  DRT_ERR_DEVICE without a GPU. */
 int        drt_scene_build_bvh_device(drt_scene *s, int32_t target_leaf_prims, int32_t bin_count, int32_t device, float *build_ms);
+/* Checks what the kernels index without checks: every triangle's material id, every material's texture index, the BVH's
+ * child and triangle ranges.  DRT_ERR_INVALID names the first offender; rendering runs the same check before uploading. */
+int        drt_scene_validate(const drt_scene *s);
 int32_t    drt_scene_triangle_count(const drt_scene *s);                      /* m_PrimitivesBuffer.size() */
 int32_t    drt_scene_node_count(const drt_scene *s);                          /* m_BVHNodes.size() */
 int32_t    drt_scene_material_count(const drt_scene *s);

@@ -60,6 +60,41 @@ def test_scene_calls_reject_bad_arguments_without_a_gpu():
     assert _code(lib.drt_debug_decode_image, b"GIF89a..", 8, C.byref(info), None, 0)[0] == drt.ERR_UNSUPPORTED
 
 
+def test_indices_the_kernels_trust_are_checked_on_the_host():
+    """drt_scene_set_geometry / _add_material accept any material id / texture index; the kernels index mats[] and texs[]
+    unchecked, so pack() (run by drt_scene_validate and before every upload) refuses what would be an out-of-bounds GPU read."""
+    def tri_scene(mat_ids, n_mats=1, tex=-1, n_tex=0):
+        sc = drt.Scene()
+        n = len(mat_ids)
+        pos = np.tile(np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], np.float32), (n, 1)) + np.arange(n, dtype=np.float32)[:, None]
+        nrm = np.tile(np.array([[0, 0, 1] * 3], np.float32), (n, 1))
+        sc.setGeometry(pos, nrm, np.zeros((n, 6), np.float32), mat_ids)
+        for _ in range(n_tex):
+            sc.addTexture(np.zeros((2, 2, 3), np.uint8))
+        for _ in range(n_mats):
+            sc.addMaterial((0.5, 0.5, 0.5), tex)
+        drt.BVHBuilder().buildIterative(sc)
+        return sc
+    tri_scene([0, 0, 0]).validate()
+    tri_scene([0, 1], n_mats=2, tex=0, n_tex=1).validate()
+    for bad in ([0, 1], [-1], [0, 7, 0]):
+        with pytest.raises(drt.DrtError) as e:
+            tri_scene(bad).validate()
+        assert e.value.code == drt.ERR_INVALID and "material" in str(e.value)
+    with pytest.raises(drt.DrtError) as e:
+        tri_scene([0], tex=0).validate()                         # texture 0 of none
+    assert e.value.code == drt.ERR_INVALID and "texture" in str(e.value)
+    with pytest.raises(drt.DrtError) as e:
+        tri_scene([0], tex=3, n_tex=2).validate()
+    assert "texture" in str(e.value)
+    sc = drt.Scene()
+    with pytest.raises(ValueError):                              # the Python mirror checks the array lengths it passes on
+        sc.setGeometry(np.zeros((2, 9), np.float32), np.zeros((2, 9), np.float32), np.zeros((2, 6), np.float32), [0, 0, 0])
+    with pytest.raises(drt.DrtError) as e:
+        drt.Scene().validate()                                   # no BVH
+    assert "build_bvh" in str(e.value)
+
+
 def test_without_a_gpu_the_renderer_refuses_to_exist():
     """No CPU fallback: on a machine without a usable HIP device creating a renderer is an error, not a slower path."""
     if drt.device_count() > 0:
