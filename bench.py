@@ -99,15 +99,22 @@ def cpu_baseline(scene_key, W, H, depth, target_seconds):
                       % (scene_key, W, H, depth, frames, samples, t_total, cores)}
 
 
-def load_traffic(workload):
-    """HBM bytes per launch from PMC counters, if a profile for this workload was collected
-    (tools/pmc_traffic.py writes profiles/traffic_<workload>.json); else None."""
-    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
-    try:
-        with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        return None
+def load_profile(workload):
+    """Per-launch counter averages of the tracing kernel on this workload (SQ instruction / lane counters, HBM bytes), written
+    by tools/roofline_from_profiles.py from rocprofv3 --pmc passes of this same bench (tools/collect_profiles.sh); else None."""
+    for rnd in ("r02",):
+        path = os.path.join(ROOT, "profiles", "%s_roofline_%s.json" % (rnd, workload))
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            d["_file"] = os.path.relpath(path, ROOT)
+            return d
+        except (OSError, ValueError):
+            pass
+    return None
+
+
+VALU_PEAK_GSLOTS = 1024 * 2.4e9 / 2 / 1e9     # 256 CUs x 4 SIMDs, 2.4 GHz, one wave64 add / mul / min / max issues every 2 cycles
 
 
 def main():
@@ -261,29 +268,62 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # The tracing kernel ALONE: with several frames in flight the launches share the GPU and neither a stream-event interval
+    # nor an execution span of one launch is a kernel time.  A few more steps, one launch at a time, blocking, untimed.
+    iso_span, iso_events, iso_launches = [], [], 0
+    if True:                                   # (every rank: the ranks stay in step; their launches are their shards)
+        iso = slots[0].r
+        iso.setFramesInFlight(1)
+        for _ in range(max(1, min(args.steps, 10 if spp * W * H < 10 ** 8 else 2))):
+            torch.cuda.synchronize()
+            with torch.cuda.stream(slots[0].stream):
+                iso.resetAccumulationBuffer()
+                iso_events.append(iso.RenderBatch(cam, scene, spp))
+            iso_span.append(iso.kernelSpanMs())
+        iso_launches = iso.launchesOfLastBatch()
+        iso.setFramesInFlight(max(1, args.frames_in_flight))
+
     if rank == 0:
         total_samples = W * H * spp if shard_world == world else W * drt.shard_rows(H, STRIPE_ROWS, shard_rank, shard_world) * spp
         ms_per_step = elapsed / args.steps * 1e3
         value = total_samples * args.steps / elapsed / 1e6
-        avg_event_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
-        avg_kernel_ms = sum(span_ms) / max(len(span_ms), 1)
-        if avg_kernel_ms <= 0:                       # pixel_walk (DRT_KERNEL=pixel_walk) has no device-side span
-            avg_kernel_ms = avg_event_ms
         roofline = None
-        if alg_bytes is not None and avg_kernel_ms > 0:
-            achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_traffic(args.workload) if world == 1 else None,
-                        "kernel": r.kernelInfo(), "kernel_ms": round(avg_kernel_ms, 4),
-                        "kernel_ms_stream_events": round(avg_event_ms, 4),
-                        "note": ("kernel_ms = mean execution span of the tracing kernel over the timed steps, first wave in to last "
-                                 "wave out on the device clock (= the duration rocprofv3 --kernel-trace reports); "
-                                 "kernel_ms_stream_events = HIP events around the step's launches on their stream (+ resolve"
-                                 + (", + time queued behind the other %d frames in flight, whose launches share the GPU: "
-                                    "--frames-in-flight 1 gives the kernel alone)" % (len(slots) - 1) if len(slots) > 1 else ")")),
-                        "achieved_aggregate": round(alg_bytes * args.steps / elapsed / 1e9, 2),
-                        "algorithmic_bytes_per_launch": int(alg_bytes),
-                        "bytes_per_sample": round(alg_bytes / max(counters["samples"], 1), 1)}
+        if iso_span and iso_launches > 0:
+            kernel_ms = sum(iso_span) / len(iso_span) / iso_launches          # per launch, device clock, first wave in .. last wave out
+            events_ms = sum(iso_events) / len(iso_events) / iso_launches      # HIP events on the launch stream (tracing + resolve kernel)
+            if kernel_ms <= 0:                                                # pixel_walk (DRT_KERNEL=pixel_walk) has no device-side span
+                kernel_ms = events_ms
+            prof = load_profile(args.workload)
+            same_kernel = bool(prof) and r.kernelInfo().split("<")[0] in prof.get("kernel", "")
+            share = total_samples / float(W * H * spp)        # a shard's launch does that part of the profiled full-frame launch's work
+            roofline = {"bound": "valu_issue", "achieved": None, "peak": round(VALU_PEAK_GSLOTS, 1), "unit": "G VALU issue slots/s (1 slot = 2 SIMD cycles)",
+                        "frac": None, "traffic": None, "kernel": r.kernelInfo(), "kernel_ms": round(kernel_ms, 4),
+                        "kernel_ms_stream_events": round(events_ms, 4), "launches_per_step": iso_launches,
+                        "kernel_ms_in_flight": round(sum(span_ms) / max(len(span_ms), 1) / iso_launches, 4),
+                        "note": ("branchy scalar fp32 / u32 code, scene and path state in LDS: vector-ALU issue bounds the kernel, HBM does not. "
+                                 "achieved = (SQ_INSTS_VALU + SQ_INSTS_VALU_FMA_F32 + 3 SQ_INSTS_VALU_TRANS_F32) per launch [rocprofv3 --pmc, profiles/] / kernel_ms "
+                                 "[this run: the tracing kernel alone, device clock; = rocprofv3 --kernel-trace duration]; issue costs 2 / 4 / 8 cycles measured "
+                                 "(tools/microbench/valu_issue.hip); compares and conversions priced at 2, so frac is a lower bound of the pipe's occupancy. "
+                                 "kernel_ms_in_flight: the same span while %d frames share the GPU (not a kernel time)" % len(slots))}
+            if same_kernel and prof.get("valu_issue_slots_per_launch"):
+                ach = prof["valu_issue_slots_per_launch"] * share / (kernel_ms * 1e-3) / 1e9
+                roofline.update({"achieved": round(ach, 1), "frac": round(ach / VALU_PEAK_GSLOTS, 4),
+                                 "lane_utilisation": round(prof.get("lane_utilisation", 0.0), 4),
+                                 "valu_wave_instructions_per_launch": int(prof["per_launch"].get("SQ_INSTS_VALU", 0) * share),
+                                 "counters_from": prof["_file"] + ("" if share == 1.0 else " (full-frame launch, scaled by this rank's share of the samples)")})
+            if same_kernel and prof.get("hbm_bytes_per_launch"):
+                roofline["traffic"] = int(prof["hbm_bytes_per_launch"] * share)
+            if alg_bytes is not None:
+                alg_launch = alg_bytes / iso_launches          # (counted on this rank's own launches)
+                hbm = {"algorithmic_bytes_per_launch": int(alg_launch), "bytes_per_sample": round(alg_bytes / max(counters["samples"], 1), 1),
+                       "achieved": round(alg_launch / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(alg_launch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "served_from": "lds" if "lds-scene" in r.kernelInfo() else "l2"}
+                if same_kernel and prof.get("hbm_bytes_per_launch_trace"):
+                    hbm["hbm_measured_frac"] = round(prof["hbm_bytes_per_launch_trace"] * share / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                hbm["note"] = ("SURVEY 8(d)'s algorithmic bytes over the kernel time; a fraction above 1 means those bytes are not served by HBM "
+                               "(served_from); hbm_measured_frac = PMC FETCH_SIZE x 2 + WRITE_SIZE of the tracing kernel over the same time")
+                roofline["hbm"] = hbm
         out = {"metric": "Msamples/sec at 1920x1080, 8spp, cornell_box" if args.workload == "cornell_box_1080p_8spp_d8" else "Msamples/sec",
                "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,

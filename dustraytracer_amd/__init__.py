@@ -219,6 +219,7 @@ _sig("drt_renderer_set_counting", C.c_int, _P, C.c_int32)
 _sig("drt_renderer_get_counters", C.c_int, _P, C.POINTER(Counters))
 _sig("drt_renderer_kernel_info", C.c_int, _P, C.c_char_p, C.c_size_t)
 _sig("drt_renderer_kernel_span", C.c_int, _P, C.POINTER(C.c_float))
+_sig("drt_renderer_launch_count", C.c_int32, _P)
 _sig("drt_renderer_set_frames_in_flight", C.c_int, _P, C.c_int32)
 _sig("drt_assemble_shards", C.c_int, _P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P)
 _sig("drt_shard_rows", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32)
@@ -459,6 +460,10 @@ class Renderer:
             out[name] = (b, l / max(b, 1), t)
         out["claim_ticks"], out["idle_polls"], out["lost_claims"], out["wave_ticks"] = int(a[24]), int(a[25]), int(a[26]), int(a[27])
         return out
+
+    def launchesOfLastBatch(self):
+        """Tracing-kernel launches the last RenderBatch was split into (per-launch sample buffer budget)."""
+        return int(_lib.drt_renderer_launch_count(self._h))
 
     def kernelSpanMs(self):
         """Device-measured execution time of the tracing kernel(s) of the last completed batch (no queueing time)."""

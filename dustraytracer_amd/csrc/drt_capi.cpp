@@ -91,6 +91,7 @@ struct drt_renderer {
     static constexpr int kMaxSpans = 64;
     unsigned long long *spans = nullptr;      // kMaxSpans x {max(~start), max(end)}: execution span of each wave_queue launch of the last batch
     int spans_used = 0;
+    int launches_last = 0;                     // tracing-kernel launches of the last batch (a batch is split by the sample budget)
     float span_ms = 0.f;                       // sum of those spans, filled by drt_renderer_wait
     int wall_clock_khz = 100000;
     static constexpr int kCounters = 256;
@@ -497,6 +498,8 @@ int drt_renderer_kernel_span(const drt_renderer *r, float *ms) {
     return DRT_OK;
 }
 
+int32_t drt_renderer_launch_count(const drt_renderer *r) { return r ? r->launches_last : 0; }
+
 int drt_renderer_kernel_info(const drt_renderer *r, char *buf, size_t cap) {
     if (!r || !buf || cap == 0) return fail(DRT_ERR_INVALID, "bad argument");
     if (r->launch_shape[1] > 0 && std::strncmp(r->kernel_name, "path_pool", 9) == 0)
@@ -616,6 +619,7 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
     HIP_TRY(hipEventRecord(r->ev_start, r->stream));                   // Renderer.cu:97
     if (r->use_pixel_walk) {
         HIP_TRY(launch_render(r->view, fp, r->bvh_depth, r->counting, r->stream, &r->kernel_name));
+        r->launches_last = 1;
     } else {
         // split the batch so that the per-sample colour buffer of one launch stays within the budget
         const size_t per_frame = (size_t)r->width * r->local_rows * 4 * sizeof(float);
@@ -627,11 +631,13 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
             r->samples_bytes = need;
         }
         r->spans_used = 0;
+        r->launches_last = 0;
         HIP_TRY(hipMemsetAsync(r->spans, 0, sizeof(unsigned long long) * 2 * drt_renderer::kMaxSpans, r->stream));
         for (uint32_t done = 0; done < n_frames; done += frames_per_launch) {
             fp.frame_first = r->frame_index + done;
             fp.n_frames = std::min(frames_per_launch, n_frames - done);
             fp.span = r->spans_used < drt_renderer::kMaxSpans ? r->spans + 2 * r->spans_used++ : nullptr;
+            r->launches_last++;
             if (r->counters_used == drt_renderer::kCounters) {      // stream order: every launch that used them is over by then
                 HIP_TRY(hipMemsetAsync(r->tile_counter, 0, sizeof(unsigned int) * drt_renderer::kCounters, r->stream));
                 r->counters_used = 0;

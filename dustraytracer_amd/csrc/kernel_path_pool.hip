@@ -717,7 +717,9 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     // launches in flight (drt_renderer_set_frames_in_flight) each gets its share of the workgroup slots, so that they run side
     // by side and the ramp-up and drain of one overlap the steady state of the others instead of queueing behind a full grid.
     uint64_t want = std::min<uint64_t>((uint64_t)num_cus * per_cu, std::max<uint64_t>(1, (n_chunks * 64ull + P - 1) / P));
-    if (fp.frames_in_flight > 1 && tune.share_grid)
+    // (only launches short enough for ramp-up and drain to matter: a launch that refills its pools a hundred times runs best
+    // on the whole chip -- room 4K / 64 spp, two frames in flight: 998 ms per step with half a grid each, 757 with full grids)
+    if (fp.frames_in_flight > 1 && tune.share_grid && n_chunks * 64ull < 64ull * (uint64_t)num_cus * per_cu * P)
         want = std::min<uint64_t>(want, std::max<uint64_t>(1, ((uint64_t)num_cus * per_cu + fp.frames_in_flight - 1) / (uint64_t)fp.frames_in_flight));
     // the part of the path state that lives in HBM: 20 bytes per pool slot of every workgroup
     const size_t slots = (size_t)num_cus * per_cu * P;

@@ -207,6 +207,8 @@ int           drt_renderer_set_frames_in_flight(drt_renderer *r, int32_t n);
  * events behind *delta_ms it does not include time the launch spent queued behind other streams' work.  0 for the
  * pixel_walk kernel. */
 int           drt_renderer_kernel_span(const drt_renderer *r, float *ms);
+/* Tracing-kernel launches of the last batch (a batch whose samples exceed the per-launch sample buffer is split). */
+int32_t       drt_renderer_launch_count(const drt_renderer *r);
 /* rank-0 side of the gather: `gathered` = world shards of padded_rows rows each (as written by the ranks' device_rgba),
  * `image` = full width*height float4.  Runs on `hip_stream`. */
 int           drt_assemble_shards(const void *gathered, void *image, uint32_t width, uint32_t height,

@@ -1,38 +1,39 @@
-# GPU box: everything profiles/ is built from, in one call.  Output under gpurun_out/prof/ (copy what is to be kept).
-#   bash tools/collect_profiles.sh
+# GPU box: everything profiles/ is built from, in one call.  Output under gpurun_out/prof/ (tools/install_profiles.py copies what is kept).
+#   bash tools/collect_profiles.sh [round-tag]
 set -e
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-# 1. the default bench line, and its kernel trace (same command under rocprofv3)
-python3 $R/bench.py > $O/bench_default.json
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_f3 -o f3 -- python3 $R/bench.py --cpu-seconds 0 > $O/bench_default_under_rocprof.json 2> /tmp/p_f3.log
-cp /tmp/p_f3/f3_kernel_stats.csv $O/bench_default_f3_kernel_stats.csv
-# 2. isolated launches
-python3 $R/bench.py --frames-in-flight 1 --cpu-seconds 0 > $O/bench_f1_isolated.json
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_f1 -o f1 -- python3 $R/bench.py --frames-in-flight 1 --cpu-seconds 0 > $O/bench_f1_under_rocprof.json 2> /tmp/p_f1.log
-cp /tmp/p_f1/f1_kernel_stats.csv $O/bench_f1_isolated_kernel_stats.csv
-# 3. HBM traffic, separate passes per counter (isolated launches so that a dispatch is one launch)
-for wl in cornell_box_1080p_8spp_d8 cs16_dust_1080p_8spp_d5; do
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch_$wl -o fetch -- python3 $R/bench.py --workload $wl --frames-in-flight 1 --cpu-seconds 0 --steps 5 --warmup 1 --no-roofline-counters > /dev/null 2> /tmp/p_fetch.log
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p_write_$wl -o write -- python3 $R/bench.py --workload $wl --frames-in-flight 1 --cpu-seconds 0 --steps 5 --warmup 1 --no-roofline-counters > /dev/null 2> /tmp/p_write.log
-  python3 $R/tools/pmc_traffic.py /tmp/p_fetch_$wl /tmp/p_write_$wl $wl $O/traffic_$wl.json > /dev/null
-  cp /tmp/p_fetch_$wl/fetch_counter_collection.csv $O/pmc_fetch_size_$wl.csv
-  cp /tmp/p_write_$wl/write_counter_collection.csv $O/pmc_write_size_$wl.csv
+SQ1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_INT32"
+SQ2="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY"
+for spec in "cornell_box_1080p_8spp_d8 6 1" "room_4k_64spp_d16 2 1"; do
+  set -- $spec; wl=$1; steps=$2; warm=$3
+  B="python3 $R/bench.py --workload $wl --frames-in-flight 1 --cpu-seconds 0 --steps $steps --warmup $warm --no-roofline-counters"
+  # the kernel alone: kernel trace of isolated launches
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_kt_$wl -o kt -- $B > $O/${TAG}_bench_f1_under_rocprof_$wl.json 2> /tmp/p_kt.log
+  cp /tmp/p_kt_$wl/kt_kernel_stats.csv $O/${TAG}_bench_f1_kernel_stats_$wl.csv
+  # counters: SQ in two passes, HBM traffic in two more (TCC has 4 slots: FETCH_SIZE takes 3, WRITE_SIZE 2)
+  rocprofv3 --pmc $SQ1 --output-format csv -d /tmp/p_sq1_$wl -o sq -- $B > /dev/null 2> /tmp/p_sq1.log
+  rocprofv3 --pmc $SQ2 --output-format csv -d /tmp/p_sq2_$wl -o sq -- $B > /dev/null 2> /tmp/p_sq2.log
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch_$wl -o fetch -- $B > /dev/null 2> /tmp/p_fetch.log
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p_write_$wl -o write -- $B > /dev/null 2> /tmp/p_write.log
+  for d in sq1 sq2 fetch write; do
+    python3 $R/tools/pmc_summary.py /tmp/p_${d}_$wl > $O/${TAG}_pmc_${d}_$wl.txt
+    f=$(find /tmp/p_${d}_$wl -name "*counter_collection.csv" | head -1); python3 $R/tools/trim_counter_csv.py $f $O/${TAG}_pmc_${d}_$wl.csv
+  done
+  python3 $R/tools/roofline_from_profiles.py $wl $O/${TAG}_bench_f1_kernel_stats_$wl.csv /tmp/p_sq1_$wl /tmp/p_sq2_$wl /tmp/p_fetch_$wl /tmp/p_write_$wl --out $O/${TAG}_roofline_$wl.json > /dev/null
 done
-# 4. SQ counters of the tracing kernel
-rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d /tmp/p_sq1 -o sq -- python3 $R/tools/time_workload.py cornell_box 1920 1080 8 > /dev/null 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS --output-format csv -d /tmp/p_sq2 -o sq -- python3 $R/tools/time_workload.py cornell_box 1920 1080 8 > /dev/null 2>&1
-python3 $R/tools/pmc_summary.py /tmp/p_sq1 /tmp/p_sq2 > $O/wave_queue_pmc_sq.txt
-# 5. phase statistics (counting build) and the other workloads
-python3 $R/tools/phase_stats.py cornell_box 8 > $O/phase_stats_cornell.txt
-python3 $R/tools/phase_stats.py cs16_dust 8 > $O/phase_stats_cs16_dust.txt
+# the default bench lines (they read the roofline JSONs written above: install them first for this run)
+cp $O/${TAG}_roofline_*.json $R/profiles/ 2>/dev/null || true
+python3 $R/bench.py > $O/${TAG}_bench_default.json
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_f3 -o f3 -- python3 $R/bench.py --cpu-seconds 0 > $O/${TAG}_bench_default_under_rocprof.json 2> /tmp/p_f3.log
+cp /tmp/p_f3/f3_kernel_stats.csv $O/${TAG}_bench_default_kernel_stats.csv
+python3 $R/bench.py --workload room_4k_64spp_d16 --cpu-seconds 10 --steps 3 --warmup 1 > $O/${TAG}_bench_room_4k_64spp_d16.json
 for wl in suzanne_plane_1080p_8spp_d2 dense_monkey_1080p_16spp_d2 cs16_dust_1080p_8spp_d5 cornell_box_256_1spp_d4 mc_transparency_843x460_50spp_d5; do
-  python3 $R/bench.py --workload $wl --cpu-seconds 3 > $O/bench_$wl.json
+  python3 $R/bench.py --workload $wl --cpu-seconds 3 > $O/${TAG}_bench_$wl.json
 done
-python3 $R/bench.py --workload room_4k_64spp_d16 --cpu-seconds 3 --steps 3 --warmup 1 > $O/bench_room_4k_64spp_d16.json
-for s in 0/2 0/4 0/8; do python3 $R/bench.py --emulate-shard $s --cpu-seconds 0 --steps 200 --warmup 20 > $O/bench_shard_${s/\//of}.json; done
-# 6. BVH build on the device: host vs GPU table, and the per-kernel times of the same command
-cd $R && python3 tools/bvh_build_bench.py > $O/bvh_build_host_vs_gpu.txt 2> /dev/null
-cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bvh -o bvh -- python3 $R/tools/bvh_build_bench.py > /dev/null 2> /tmp/p_bvh.log
-cp /tmp/p_bvh/bvh_kernel_stats.csv $O/bvh_build_kernel_stats.csv
+for s in 0/2 0/4 0/8; do python3 $R/bench.py --emulate-shard $s --cpu-seconds 0 --steps 200 --warmup 20 > $O/${TAG}_bench_shard_${s/\//of}.json; done
+python3 $R/tools/pool_stats.py cornell_box 1920 1080 8 8 > $O/${TAG}_pool_stats_cornell.txt 2>&1
+python3 $R/tools/pool_stats.py room 1920 1080 4 16 > $O/${TAG}_pool_stats_room.txt 2>&1
+python3 $R/tools/small_launches.py > $O/${TAG}_small_launches.txt 2>&1
 ls -la $O
