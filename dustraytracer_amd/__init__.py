@@ -226,6 +226,7 @@ _sig("drt_shard_rows", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint3
 _sig("drt_debug_decode_image", C.c_int, _P, C.c_size_t, _P, _P, C.c_size_t)
 _sig("drt_debug_kat", C.c_int, C.c_int32, C.c_int32, _P, C.c_size_t, _P, C.c_size_t, C.c_uint32, C.POINTER(_CameraPOD), C.c_uint32, C.c_uint32)
 _sig("drt_debug_hash_cycles", C.c_int, C.c_int32, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32))
+_sig("drt_debug_wave_queue_plans", C.c_int, _P, C.c_char_p, C.c_size_t)
 _sig("drt_debug_pool_stats", C.c_int, _P, _P, C.c_int32)
 _sig("drt_debug_check_rcp", C.c_int, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 _sig("drt_debug_check_sqrt", C.c_int, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
@@ -449,6 +450,13 @@ class Renderer:
         """Hint that n launches are kept in flight on this device (other renderers on other streams): small launches get
         smaller grids so that they overlap.  Does not change results."""
         _check(_lib.drt_renderer_set_frames_in_flight(self._h, int(n)))
+
+    def waveQueuePlans(self):
+        """The launch packagings of wave_queue timed so far (list of plans; see drt_debug_wave_queue_plans)."""
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        _check(_lib.drt_debug_wave_queue_plans(self._h, buf, len(buf)))
+        return json.loads(buf.value.decode())
 
     def poolStats(self, reset=True):
         """path_pool statistics (renderer created with DRT_POOL_STATS=1): dict queue -> (batches, mean paths per batch, ticks)."""

@@ -105,6 +105,7 @@ struct drt_renderer {
     bool use_pixel_walk = false;              // DRT_KERNEL=pixel_walk selects the first (non-persistent) kernel
     int use_path_pool = 1;                    // path_pool where it applies (lean paths, scene in LDS); DRT_KERNEL=wave_queue: never
     unsigned int *pool_status = nullptr;      // device word: set by an aborted path_pool launch
+    WaveQueueCache wq_cache;                  // measured choice among wave_queue's launch packagings
     PoolScratch pool_scratch;
     PoolTuning pool_tuning;                   // DRT_POOL_THREADS / _PATHS / _MIN_FILL / _PATIENCE
     uint32_t pool_t_class[3] = { 0, 0, 0 };   // leaf-size classes of the uploaded scene (path_pool's T queues)
@@ -649,7 +650,7 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
                                          r->num_cus, r->stream, &r->kernel_name, r->launch_shape));
             else
             HIP_TRY(launch_wave_queue(r->view, fp, r->bvh_depth, r->counting ? 2 : 0, r->scene_has_alpha, queue_head,
-                                      r->samples, r->num_cus, r->stream, &r->kernel_name, r->launch_shape));
+                                      r->samples, r->num_cus, r->stream, &r->kernel_name, r->launch_shape, r->wq_cache));
         }
     }
     HIP_TRY(hipEventRecord(r->ev_stop, r->stream));                    // Renderer.cu:105
@@ -688,6 +689,7 @@ int drt_renderer_wait(drt_renderer *r, float *delta_ms) {
         }
         r->span_ms = (float)(ticks / (double)r->wall_clock_khz);
     }
+    wave_queue_report(r->wq_cache, r->span_ms);
     r->pending = false;
     if (r->use_path_pool) {
         unsigned int status = 0;
@@ -783,6 +785,26 @@ int drt_debug_kat(int32_t device, int32_t which, const void *in, size_t in_bytes
     (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
     if (e != hipSuccess) return fail(DRT_ERR_DEVICE, hipGetErrorString(e));
+    return DRT_OK;
+}
+
+int drt_debug_wave_queue_plans(const drt_renderer *r, char *buf, size_t cap) {
+    if (!r || !buf || cap == 0) return fail(DRT_ERR_INVALID, "bad argument");
+    std::string out = "[";
+    for (const WqPlan &p : r->wq_cache.plans) {
+        if (out.size() > 1) out += ", ";
+        out += "{\"key\": " + std::to_string(p.key) + ", \"chosen\": " + std::to_string(p.chosen) + ", \"candidates\": [";
+        for (size_t i = 0; i < p.cands.size(); i++) {
+            char item[200];
+            std::snprintf(item, sizeof item, "%s{\"threads\": %d, \"entry_bytes\": %d, \"tris\": %d, \"wg_per_cu\": %d, \"trials\": %d, \"ns_per_sample\": %.6f}",
+                          i ? ", " : "", p.cands[i].threads, p.cands[i].entry_bytes, p.cands[i].tris, p.cands[i].per_cu, p.trials[i], p.ns_per_sample[i]);
+            out += item;
+        }
+        out += "]}";
+    }
+    out += "]";
+    if (out.size() + 1 > cap) return fail(DRT_ERR_INVALID, "destination too small");
+    std::memcpy(buf, out.c_str(), out.size() + 1);
     return DRT_OK;
 }
 

@@ -33,6 +33,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "device_access.hpp"
 #include "device_math.hpp"
@@ -729,83 +730,105 @@ hipError_t launch_config(const SceneView &sc, const FrameParams &fp, unsigned in
     return hipGetLastError();
 }
 
+// ---- packaging of a launch: workgroup size, stack entry size, triangles per T step ----
+// Every packaging computes the same bits (tests/test_gpu_parity.py), so which one runs is a matter of time only, and a
+// renderer launches the same kind of work over and over: the legal candidates of a (kernel, scene, view class) are each TIMED
+// on the first launches that are big enough to tell (their execution span, drt_renderer_kernel_span) and the fastest is kept
+// (WaveQueueCache, one per renderer -- nothing here is shared between renderers, devices or threads).
+//  * Workgroup size.  Every workgroup stages its own copy of an LDS scene next to its lanes' stacks, so a scene of some size
+//    (room: 17.6 KB) is amortised over twice the waves by a 512-thread group.  (Waves never synchronise after the staging.)
+//  * Stack entry size.  A deep tree read from HBM is limited by its stacks alone (16 levels x 8 B x 256 lanes = 32 KB per
+//    group: 5 per CU); 6-byte entries (16-bit references, when they fit) make it 6, at one more LDS operation per access.
+//  * Triangles per T step.  Three at 94 VGPRs (one wave per SIMD less) for trees read from HBM: more loads in flight per
+//    memory round trip.
+// Round 1 chose among them by rules fitted to four views (camera inside the scene's bounds or not); what used to be the rule
+// is now only the order in which the candidates are tried.
+template <int MODE, bool LDS_SCENE>
+std::vector<WqVariant> wave_queue_candidates(const SceneView &sc, uint32_t stack_entries, size_t scene_lds_bytes, bool camera_inside) {
+    constexpr bool kLean = MODE == 0 || MODE == 3 || MODE == 4 || MODE == 5;
+    static const bool only_small = std::getenv("DRT_WG_THREADS") && std::atoi(std::getenv("DRT_WG_THREADS")) == kThreads;      // A/B switches
+    static const bool only_wide = std::getenv("DRT_STACK_REF16") && std::atoi(std::getenv("DRT_STACK_REF16")) == 0;
+    static const bool wide_allowed = !(std::getenv("DRT_TRIS_WIDE") && std::atoi(std::getenv("DRT_TRIS_WIDE")) == 0);
+    std::vector<WqVariant> out;
+    auto add = [&](int threads, int entry, int tris, int per_cu) {
+        if (per_cu < 1) return;
+        if (const char *cap = std::getenv("DRT_MAX_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, std::atoi(cap)));
+        out.push_back(WqVariant{ threads, entry, tris, per_cu });
+    };
+    const int plain = groups_per_cu<MODE, LDS_SCENE, false>(kThreads, (size_t)stack_entries * kThreads * 8 + scene_lds_bytes);
+    add(kThreads, 8, 2, plain);
+    if (LDS_SCENE && scene_lds_bytes >= 4096 && !only_small) {
+        const int n = groups_per_cu<MODE, LDS_SCENE, false>(kBigThreads, (size_t)stack_entries * kBigThreads * 8 + scene_lds_bytes);
+        if (n * kBigThreads > plain * kThreads) add(kBigThreads, 8, 2, n);                 // only when it keeps more waves resident
+    }
+    if (kLean && !LDS_SCENE && !only_wide && sc.n_inner < 0x8000u && sc.n_leaves < 0x8000u) {
+        const int n = groups_per_cu<MODE, LDS_SCENE, kLean && !LDS_SCENE>(kThreads, (size_t)stack_entries * kThreads * 6 + scene_lds_bytes);
+        if (n > plain) add(kThreads, 6, 2, n);
+    }
+    if (MODE == 0 && !LDS_SCENE && wide_allowed)
+        add(kThreads, 8, 3, groups_per_cu<MODE, LDS_SCENE, false, (MODE == 0 && !LDS_SCENE) ? 3 : 2>(kThreads, (size_t)stack_entries * kThreads * 8 + scene_lds_bytes));
+    if (out.empty()) out.push_back(WqVariant{ kThreads, 8, 2, 1 });
+    // the order of the trials = round 1's rules: from inside, more waves first; from outside (sky around), more loads in flight first
+    auto rank = [&](const WqVariant &v) { return camera_inside ? (v.entry_bytes == 6 ? 0 : (v.threads == kBigThreads ? 1 : (v.tris == 3 ? 3 : 2)))
+                                                               : (v.tris == 3 ? 0 : (v.threads == kBigThreads ? 1 : (v.entry_bytes == 6 ? 3 : 2))); };
+    std::stable_sort(out.begin(), out.end(), [&](const WqVariant &a, const WqVariant &b) { return rank(a) < rank(b); });
+    return out;
+}
+
 template <int MODE, bool LDS_SCENE>
 hipError_t launch_one(const SceneView &sc, const FrameParams &fp, unsigned int *chunk_counter, float4 *samples,
-                      uint32_t stack_entries, size_t scene_lds_bytes, int num_cus, hipStream_t stream, int *launch_shape) {
-    // Two packaging choices, both made for the number of waves a CU keeps resident (ties: the plain one).
-    //  * Workgroup size.  Every workgroup stages its own copy of an LDS scene next to its lanes' stacks, so a scene of some
-    //    size (room: 17.6 KB) is amortised over twice the waves by a 512-thread group: room 4 -> 6 waves per SIMD.  (Waves
-    //    never synchronise after the staging.)
-    //  * Stack entry size.  A deep tree read from HBM is limited by its stacks alone (16 levels x 8 B x 256 lanes = 32 KB per
-    //    group: 5 per CU); 6-byte entries (16-bit references, when they fit) make it 6 ...
+                      uint32_t stack_entries, size_t scene_lds_bytes, int num_cus, hipStream_t stream, int *launch_shape, WaveQueueCache &cache) {
     constexpr bool kLean = MODE == 0 || MODE == 3 || MODE == 4 || MODE == 5;
-    static int cached_threads = 0, cached_per_cu = 0, cached_entry_bytes = 8;          // one set per instantiation
-    static size_t cached_key = ~(size_t)0;
-    // ... where traversal is what the launch is made of: with the camera inside the scene's bounds every primary ray walks the
-    // tree (cs16_dust, a closed map: -10 %).  Seen from outside with sky around it (dense_monkey: 1.2 rays per sample) the
-    // extra waves gain nothing and the second LDS operation per stack access costs 5 %.
     bool camera_inside = true;
     for (int k = 0; k < 3; k++) camera_inside = camera_inside && fp.cam_pos[k] >= sc.root_min[k] && fp.cam_pos[k] <= sc.root_max[k];
-    const bool refs_fit_16 = kLean && !LDS_SCENE && camera_inside && sc.n_inner < 0x8000u && sc.n_leaves < 0x8000u;
-    const size_t key = (scene_lds_bytes * 131u + stack_entries) * 2u + (refs_fit_16 ? 1u : 0u);
-    if (cached_threads == 0 || cached_key != key) {
-        static const bool only_small = std::getenv("DRT_WG_THREADS") && std::atoi(std::getenv("DRT_WG_THREADS")) == kThreads;      // A/B switches
-        static const bool only_wide = std::getenv("DRT_STACK_REF16") && std::atoi(std::getenv("DRT_STACK_REF16")) == 0;
-        int best_threads = kThreads, best_entry = 8;
-        int best_per_cu = std::max(1, groups_per_cu<MODE, LDS_SCENE, false>(kThreads, (size_t)stack_entries * kThreads * 8 + scene_lds_bytes));
-        int best_waves = best_per_cu * kThreads / 64;
-        if (LDS_SCENE && scene_lds_bytes >= 4096 && !only_small) {
-            const int n = groups_per_cu<MODE, LDS_SCENE, false>(kBigThreads, (size_t)stack_entries * kBigThreads * 8 + scene_lds_bytes);
-            if (n * kBigThreads / 64 > best_waves) { best_waves = n * kBigThreads / 64; best_threads = kBigThreads; best_per_cu = n; }
-        }
-        if (refs_fit_16 && !only_wide) {
-            const int n = groups_per_cu<MODE, LDS_SCENE, kLean && !LDS_SCENE>(kThreads, (size_t)stack_entries * kThreads * 6 + scene_lds_bytes);
-            if (n * kThreads / 64 > best_waves) { best_waves = n * kThreads / 64; best_threads = kThreads; best_per_cu = n; best_entry = 6; }
-        }
-        if (const char *cap = std::getenv("DRT_MAX_BLOCKS_PER_CU")) best_per_cu = std::max(1, std::min(best_per_cu, std::atoi(cap)));
-        cached_threads = best_threads; cached_per_cu = best_per_cu; cached_entry_bytes = best_entry; cached_key = key;
+    // one plan per (kernel, scene shape, view class)
+    const uint64_t key = ((((uint64_t)scene_lds_bytes * 131u + stack_entries) * 131u + sc.n_tris) * 16u + (uint64_t)MODE * 2u + (LDS_SCENE ? 1u : 0u)) * 2u + (camera_inside ? 1u : 0u);
+    WqPlan *plan = nullptr;
+    for (WqPlan &p : cache.plans) if (p.key == key) plan = &p;
+    if (!plan) {
+        if (cache.plans.size() >= 32) cache.plans.erase(cache.plans.begin());
+        cache.plans.emplace_back();
+        plan = &cache.plans.back();
+        plan->key = key;
+        plan->cands = wave_queue_candidates<MODE, LDS_SCENE>(sc, stack_entries, scene_lds_bytes, camera_inside);
+        plan->ns_per_sample.assign(plan->cands.size(), -1.0);
+        plan->trials.assign(plan->cands.size(), 0);
+        plan->chosen = plan->cands.size() == 1 ? 0 : -1;
     }
-    const int threads = cached_threads;
-    int per_cu = cached_per_cu;
-    const size_t lds_bytes = (size_t)stack_entries * threads * cached_entry_bytes + scene_lds_bytes;
-    //  * Triangles per T step.  Seen from outside (primary rays that mostly miss or end after a bounce: suzanne, dense_monkey)
-    //    the plain kernel reading its tree from HBM is bound by the round trips of its leaf loops, not by occupancy: three
-    //    triangles per step at one wave less is 11 % / 2 % faster there.  From inside (cs16_dust) the extra wave is worth
-    //    more (+9 % the other way), and the alpha-test kernels lose 2 % (tools/ab_hbm_libs.sh).  DRT_TRIS_WIDE=0 disables.
-    constexpr bool kWideCandidate = MODE == 0 && !LDS_SCENE;
-    static const bool wide_allowed = !(std::getenv("DRT_TRIS_WIDE") && std::atoi(std::getenv("DRT_TRIS_WIDE")) == 0);
-    if (kWideCandidate && wide_allowed && !camera_inside && cached_entry_bytes == 8) {
-        static int wide_per_cu = -1;
-        static size_t wide_key = ~(size_t)0;
-        if (wide_per_cu < 0 || wide_key != key) { wide_per_cu = groups_per_cu<MODE, LDS_SCENE, false, kWideCandidate ? 3 : 2>(threads, lds_bytes); wide_key = key; }
-        if (wide_per_cu > 0) {
-            per_cu = wide_per_cu;
-            if (launch_shape) { launch_shape[0] = (int)stack_entries; launch_shape[1] = per_cu; launch_shape[2] = (int)(lds_bytes / 1024); launch_shape[3] = threads + 2; }
-            return launch_config<MODE, LDS_SCENE, false, kWideCandidate ? 3 : 2>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, threads, per_cu, num_cus, stream);
-        }
+    int use = plan->chosen;
+    if (use < 0) {                      // still measuring: the candidate with the fewest trials so far (the batch keeps one candidate)
+        if (cache.batch_key == key && cache.batch_cand >= 0) use = cache.batch_cand;
+        else { use = 0; for (size_t i = 1; i < plan->cands.size(); i++) if (plan->trials[i] < plan->trials[(size_t)use]) use = (int)i; }
     }
-    if (launch_shape) { launch_shape[0] = (int)stack_entries; launch_shape[1] = per_cu; launch_shape[2] = (int)(lds_bytes / 1024); launch_shape[3] = threads + (cached_entry_bytes == 6 ? 1 : 0); }
-    if (cached_entry_bytes == 6)
-        return launch_config<MODE, LDS_SCENE, kLean && !LDS_SCENE>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, threads, per_cu, num_cus, stream);
-    return launch_config<MODE, LDS_SCENE, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, threads, per_cu, num_cus, stream);
+    cache.batch_key = key; cache.batch_cand = use;
+    cache.batch_samples += (double)fp.width * fp.local_rows * fp.n_frames;
+    const WqVariant v = plan->cands[(size_t)use];
+    const size_t lds_bytes = (size_t)stack_entries * v.threads * v.entry_bytes + scene_lds_bytes;
+    if (launch_shape) { launch_shape[0] = (int)stack_entries; launch_shape[1] = v.per_cu; launch_shape[2] = (int)(lds_bytes / 1024); launch_shape[3] = v.threads + (v.entry_bytes == 6 ? 1 : 0) + (v.tris == 3 ? 2 : 0); }
+    if (v.tris == 3)
+        return launch_config<MODE, LDS_SCENE, false, (MODE == 0 && !LDS_SCENE) ? 3 : 2>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, v.threads, v.per_cu, num_cus, stream);
+    if (v.entry_bytes == 6)
+        return launch_config<MODE, LDS_SCENE, kLean && !LDS_SCENE>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, v.threads, v.per_cu, num_cus, stream);
+    return launch_config<MODE, LDS_SCENE, false>(sc, fp, chunk_counter, samples, stack_entries, lds_bytes, v.threads, v.per_cu, num_cus, stream);
 }
 
 hipError_t launch_mode(const SceneView &sc, const FrameParams &fp, int mode, bool lds_scene, unsigned int *chunk_counter,
-                       float4 *samples, uint32_t stack_entries, size_t scene_lds_bytes, int num_cus, hipStream_t stream, int *launch_shape) {
+                       float4 *samples, uint32_t stack_entries, size_t scene_lds_bytes, int num_cus, hipStream_t stream, int *launch_shape,
+                       WaveQueueCache &cache) {
     if (lds_scene) {
-        if (mode == 0) return launch_one<0, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
-        if (mode == 1) return launch_one<1, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
-        if (mode == 3) return launch_one<3, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
-        if (mode == 4) return launch_one<4, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
-        if (mode == 5) return launch_one<5, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
-        return launch_one<2, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
+        if (mode == 0) return launch_one<0, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape, cache);
+        if (mode == 1) return launch_one<1, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape, cache);
+        if (mode == 3) return launch_one<3, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape, cache);
+        if (mode == 4) return launch_one<4, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape, cache);
+        if (mode == 5) return launch_one<5, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape, cache);
+        return launch_one<2, true>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape, cache);
     }
-    if (mode == 0) return launch_one<0, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
-    if (mode == 1) return launch_one<1, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
-    if (mode == 3) return launch_one<3, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
-    if (mode == 4) return launch_one<4, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
-    if (mode == 5) return launch_one<5, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
-    return launch_one<2, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape);
+    if (mode == 0) return launch_one<0, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape, cache);
+    if (mode == 1) return launch_one<1, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape, cache);
+    if (mode == 3) return launch_one<3, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape, cache);
+    if (mode == 4) return launch_one<4, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape, cache);
+    if (mode == 5) return launch_one<5, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape, cache);
+    return launch_one<2, false>(sc, fp, chunk_counter, samples, stack_entries, scene_lds_bytes, num_cus, stream, launch_shape, cache);
 }
 
 }  // namespace
@@ -836,9 +859,31 @@ size_t wave_queue_sample_bytes(const FrameParams &fp) {
     return (size_t)fp.width * fp.local_rows * fp.n_frames * sizeof(float4);
 }
 
+// A batch is over and its tracing kernels took span_ms on the device: feed the measurement to the plan that is still choosing.
+void wave_queue_report(WaveQueueCache &cache, float span_ms) {
+    const uint64_t key = cache.batch_key;
+    const int cand = cache.batch_cand;
+    const double samples = cache.batch_samples;
+    cache.batch_cand = -1; cache.batch_samples = 0;
+    if (cand < 0 || span_ms <= 0.f || samples < 262144.0) return;          // too small a launch says nothing about steady-state speed
+    for (WqPlan &p : cache.plans) {
+        if (p.key != key || p.chosen >= 0 || (size_t)cand >= p.cands.size()) continue;
+        const double t = (double)span_ms * 1e6 / samples;
+        double &best = p.ns_per_sample[(size_t)cand];
+        best = best < 0 ? t : std::min(best, t);
+        p.trials[(size_t)cand]++;
+        bool done = true;
+        for (int n : p.trials) done = done && n >= 2;                       // two timed launches each
+        if (done) {
+            p.chosen = 0;
+            for (size_t i = 1; i < p.cands.size(); i++) if (p.ns_per_sample[i] < p.ns_per_sample[(size_t)p.chosen]) p.chosen = (int)i;
+        }
+    }
+}
+
 hipError_t launch_wave_queue(const SceneView &sc, const FrameParams &fp, int bvh_depth, int mode, bool scene_has_alpha,
                              unsigned int *chunk_counter, void *samples, int num_cus, hipStream_t stream, const char **kernel_name,
-                             int *launch_shape) {
+                             int *launch_shape, WaveQueueCache &cache) {
     if (fp.width == 0 || fp.local_rows == 0 || fp.n_frames == 0) return hipSuccess;
     if (mode == 0 && fp.render_mode != 0) mode = 1;                                    // debug views: the general kernel
     if (mode == 0) mode = fp.enable_sunlight ? (scene_has_alpha ? 5 : 4) : (scene_has_alpha ? 3 : 0);
@@ -858,7 +903,7 @@ hipError_t launch_wave_queue(const SceneView &sc, const FrameParams &fp, int bvh
     float4 *s4 = static_cast<float4 *>(samples);
     // (the one-frame shortcut of path_pool -- accumulate and resolve inside the tracing kernel -- costs this kernel a register
     // too many: its 6-byte-stack variants go from 80 to 81 VGPRs = 6 -> 5 waves per SIMD)
-    e = launch_mode(sc, fp, mode, lds_scene, chunk_counter, s4, (uint32_t)stack, lds_scene ? scene_bytes : 0, num_cus, stream, launch_shape);
+    e = launch_mode(sc, fp, mode, lds_scene, chunk_counter, s4, (uint32_t)stack, lds_scene ? scene_bytes : 0, num_cus, stream, launch_shape, cache);
     if (e != hipSuccess) return e;
     return launch_resolve(fp, samples, stream);
 }

@@ -12,13 +12,19 @@ hipError_t launch_render(const SceneView &scene, const FrameParams &frame, int b
 
 // wave_queue (kernel_wave_queue.hip): persistent waves + tile queue + phase voting.
 // mode 0 = lean (auto-upgraded to 1 when a setting or the scene needs it), 1 = general, 2 = general + work counters.
+// which packaging of a wave_queue launch is fastest is measured, once per (kernel, scene shape, view class); one cache per renderer
+struct WqVariant { int threads, entry_bytes, tris, per_cu; };
+struct WqPlan { uint64_t key = 0; std::vector<WqVariant> cands; std::vector<double> ns_per_sample; std::vector<int> trials; int chosen = -1; };
+struct WaveQueueCache { std::vector<WqPlan> plans; uint64_t batch_key = 0; int batch_cand = -1; double batch_samples = 0; };
+void wave_queue_report(WaveQueueCache &cache, float span_ms);
 constexpr size_t kLdsSceneBytes = 40 * 1024;     // stage the traversal data in LDS when it is at most this big
 // `samples` must hold wave_queue_sample_bytes(frame) bytes (one float4 per pixel and frame of the launch); the launch
 // runs the tracing kernel and then the ordered resolve kernel on `stream`.
 size_t wave_queue_sample_bytes(const FrameParams &frame);
 hipError_t launch_wave_queue(const SceneView &scene, const FrameParams &frame, int bvh_depth, int mode, bool scene_has_alpha,
                              unsigned int *chunk_counter, void *samples, int num_cus, hipStream_t stream, const char **kernel_name,
-                             int *launch_shape /* out[4], may be null: stack slots per lane, workgroups per CU, LDS KiB per workgroup, threads per workgroup */);
+                             int *launch_shape /* out[4], may be null: stack slots per lane, workgroups per CU, LDS KiB per workgroup, threads per workgroup */,
+                             WaveQueueCache &cache);
 
 hipError_t launch_resolve(const FrameParams &frame, void *samples, hipStream_t stream);
 size_t wave_queue_scene_lds_bytes(const SceneView &scene);

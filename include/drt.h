@@ -227,6 +227,10 @@ int           drt_debug_kat(int32_t device, int32_t which, const void *in, size_
                             const drt_camera *cam, uint32_t width, uint32_t height);
 /* Every 32-bit value on a cycle of the RNG hash (Random.cu:6-11) no longer than max_len: (value, length) pairs. */
 int           drt_debug_hash_cycles(int32_t device, uint32_t max_len, uint32_t *pairs_out, uint32_t cap_pairs, uint32_t *found);
+/* The wave_queue launch packagings (workgroup size, stack entry bytes, triangles per step) this renderer has timed so far, as
+ * JSON text: one plan per (kernel, scene shape, view class) with its candidates, their trials and best ns per sample, and
+ * the index of the one kept (-1 = still measuring).  All candidates compute the same image. */
+int           drt_debug_wave_queue_plans(const drt_renderer *r, char *buf, size_t cap);
 /* path_pool kernel statistics of a renderer created with DRT_POOL_STATS=1 in the environment: per queue (N, T0..T3, B, E, R)
  * {batches, paths served, shader-clock ticks}, then ticks spent claiming, idle polls, lost claims, wave ticks. */
 int           drt_debug_pool_stats(drt_renderer *r, uint64_t out[32], int32_t reset);
