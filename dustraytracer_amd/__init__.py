@@ -226,6 +226,20 @@ _sig("drt_shard_rows", C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint3
 _sig("drt_debug_decode_image", C.c_int, _P, C.c_size_t, _P, _P, C.c_size_t)
 _sig("drt_debug_kat", C.c_int, C.c_int32, C.c_int32, _P, C.c_size_t, _P, C.c_size_t, C.c_uint32, C.POINTER(_CameraPOD), C.c_uint32, C.c_uint32)
 _sig("drt_debug_hash_cycles", C.c_int, C.c_int32, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_uint32))
+_sig("drt_group_create", _P, C.POINTER(C.c_int32), C.c_int32)
+_sig("drt_group_destroy", None, _P)
+_sig("drt_group_size", C.c_int32, _P)
+_sig("drt_group_renderer", _P, _P, C.c_int32)
+_sig("drt_group_resize", C.c_int, _P, C.c_uint32, C.c_uint32)
+_sig("drt_group_set_settings", C.c_int, _P, _P)
+_sig("drt_group_reset", C.c_int, _P)
+_sig("drt_group_render_batch", C.c_int, _P, _P, _P, C.c_uint32, C.POINTER(C.c_float))
+_sig("drt_group_render_batch_async", C.c_int, _P, _P, _P, C.c_uint32)
+_sig("drt_group_wait", C.c_int, _P, C.POINTER(C.c_float))
+_sig("drt_group_sample_count", C.c_uint32, _P)
+_sig("drt_group_device_rgba", _P, _P)
+_sig("drt_group_read_rgba32f", C.c_int, _P, _P, C.c_size_t)
+_sig("drt_shard_stripe", C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 _sig("drt_debug_wave_queue_plans", C.c_int, _P, C.c_char_p, C.c_size_t)
 _sig("drt_debug_pool_stats", C.c_int, _P, _P, C.c_int32)
 _sig("drt_debug_check_rcp", C.c_int, C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
@@ -355,6 +369,76 @@ class BVHBuilder:
         return scene
 
     build = buildIterative      # BVHBuilder.cu:100-173 produces the same tree through recursion
+
+
+def shard_stripe(width, height, stripe_rows, rank, world, k):
+    """(offset in the rank's compact shard, offset in the full image, length) of the rank's k-th stripe, in floats of an
+    RGBA32F frame; None when the rank has no k-th stripe."""
+    so, do, cnt = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    if not _lib.drt_shard_stripe(width, height, stripe_rows, rank, world, k, C.byref(so), C.byref(do), C.byref(cnt)):
+        return None
+    return int(so.value), int(do.value), int(cnt.value)
+
+
+class RendererGroup:
+    """Several GPUs of one node behind the Renderer interface (drt_group_*): one process, a renderer per device, stripes
+    gathered into the first device's image over RCCL.  Same calls as Renderer."""
+
+    def __init__(self, devices=(0,)):
+        arr = (C.c_int32 * len(devices))(*devices)
+        self._h = _lib.drt_group_create(arr, len(devices))
+        if not self._h:
+            raise DrtError(ERR_DEVICE, (_lib.drt_last_error() or b"").decode())
+        self.m_RendererSettings = RendererSettings()
+        self._w = self._h_px = 0
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            _lib.drt_group_destroy(h)
+
+    def size(self):
+        return int(_lib.drt_group_size(self._h))
+
+    def ResizeBuffer(self, width, height):
+        _check(_lib.drt_group_resize(self._h, width, height))
+        self._w, self._h_px = width, height
+
+    def resetAccumulationBuffer(self):
+        _check(_lib.drt_group_reset(self._h))
+
+    def getSampleCount(self):
+        return int(_lib.drt_group_sample_count(self._h))
+
+    def RenderBatch(self, cam, scene, n_frames):
+        _check(_lib.drt_group_set_settings(self._h, C.byref(self.m_RendererSettings)))
+        ms = C.c_float(0)
+        pod = cam._pod()
+        _check(_lib.drt_group_render_batch(self._h, C.byref(pod), scene._h, int(n_frames), C.byref(ms)))
+        return ms.value
+
+    def Render(self, cam, scene):
+        return self.RenderBatch(cam, scene, 1)
+
+    def RenderBatchAsync(self, cam, scene, n_frames):
+        _check(_lib.drt_group_set_settings(self._h, C.byref(self.m_RendererSettings)))
+        pod = cam._pod()
+        _check(_lib.drt_group_render_batch_async(self._h, C.byref(pod), scene._h, int(n_frames)))
+
+    def Wait(self):
+        ms = C.c_float(0)
+        _check(_lib.drt_group_wait(self._h, C.byref(ms)))
+        return ms.value
+
+    def GetRenderTargetImage(self):
+        out = np.zeros((self._h_px, self._w, 4), np.float32)
+        _check(_lib.drt_group_read_rgba32f(self._h, out.ctypes.data, out.size))
+        return out
+
+    def kernelInfo(self, index=0):
+        buf = C.create_string_buffer(128)
+        _check(_lib.drt_renderer_kernel_info(_lib.drt_group_renderer(self._h, index), buf, 128))
+        return buf.value.decode()
 
 
 class Renderer:

@@ -140,6 +140,7 @@ struct drt_renderer {
 extern "C" {
 
 int drt_abi_version(void) { return DRT_ABI_VERSION; }
+int drt_internal_fail(int code, const char *msg) { return fail(code, msg ? msg : ""); }      // for the library's other translation units
 const char *drt_last_error(void) { return g_error.c_str(); }
 
 int drt_device_count(void) {

@@ -2,6 +2,7 @@
 // (.png output reproduces the editor's "save png": 8-bit clamp of the GL read-back + vertical flip, EditorLayer.cpp:23-31,85-96)
 //   g++ -std=c++17 -Iinclude examples/drt_render.cpp -Ldustraytracer_amd -ldrt_hip -Wl,-rpath,$PWD/dustraytracer_amd -o drt_render
 //   ./drt_render models/cornell_box.glb out.pfm 1920 1080 8 8  3.6 1.25 0  -1 0 0
+//   DRT_DEVICES=0,1,2,3,4,5,6,7 ./drt_render models/room.glb out.pfm 3840 2160 64 16  0 1.4 2  0 0 -1     (all GPUs of the node: stripes + RCCL gather)
 #include <DustRayTracer.hpp>
 
 #include <algorithm>
@@ -75,7 +76,11 @@ int main(int argc, char **argv) {
             cam.m_Position = { (float)std::atof(argv[7]), (float)std::atof(argv[8]), (float)std::atof(argv[9]) };
             cam.m_Forward_dir = { (float)std::atof(argv[10]), (float)std::atof(argv[11]), (float)std::atof(argv[12]) };
         }
-        Renderer renderer(0);
+        std::vector<int> devices;                         // DRT_DEVICES=0,1,...: several GPUs of the node behind the same Renderer calls
+        if (const char *list = std::getenv("DRT_DEVICES"))
+            for (const char *p = list; *p;) { devices.push_back(std::atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; }
+        if (devices.empty()) devices.push_back(0);
+        Renderer renderer(devices);
         renderer.m_RendererSettings.ray_bounce_limit = std::atoi(argv[6]);
         renderer.m_RendererSettings.max_samples = (int)spp + 1;
         renderer.ResizeBuffer(W, H);
@@ -83,8 +88,8 @@ int main(int argc, char **argv) {
         renderer.RenderBatch(&cam, scene, spp, &ms);
         std::vector<float> rgba((size_t)W * H * 4);
         renderer.ReadRenderTarget(rgba.data());
-        std::printf("%zu triangles, %u x %u, %u spp: %.3f ms (%.1f Msamples/s)\n", scene.trianglesCount(), W, H, spp, ms,
-                    (double)W * H * spp / ms / 1e3);
+        std::printf("%zu triangles, %u x %u, %u spp on %d GPU%s: %.3f ms (%.1f Msamples/s)\n", scene.trianglesCount(), W, H, spp,
+                    renderer.deviceCount(), renderer.deviceCount() > 1 ? "s" : "", ms, (double)W * H * spp / ms / 1e3);
         const std::string out(argv[2]);
         if (out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0) {
             // glGetTexImage(GL_RGBA, GL_UNSIGNED_BYTE) clamps to [0,1] and rounds to 8 bits; stbi_flip_vertically_on_write(true)

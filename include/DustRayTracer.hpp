@@ -186,37 +186,51 @@ public:
     const void *build(Scene::Part &primitives, Scene::Part &nodes) { return buildIterative(primitives, nodes); }
 };
 
-// Core/Renderer.hpp:14-47
+// Core/Renderer.hpp:14-47.  Renderer(device) renders on one GPU; Renderer({0, 1, ..., 7}) renders on several GPUs of the
+// node (drt_group_*: framebuffer stripes per device, gathered into the first device's image over RCCL) behind the same calls.
 class Renderer {
 public:
     explicit Renderer(int device = 0) : handle(drt_renderer_create(device)) { if (!handle) throw drt::Error(DRT_ERR_DEVICE, drt_last_error()); }
-    ~Renderer() { drt_renderer_destroy(handle); }
+    explicit Renderer(const std::vector<int> &devices) {
+        std::vector<int32_t> d(devices.begin(), devices.end());
+        group = drt_group_create(d.data(), (int32_t)d.size());
+        if (!group) throw drt::Error(DRT_ERR_DEVICE, drt_last_error());
+        handle = drt_group_renderer(group, 0);
+    }
+    ~Renderer() { if (group) drt_group_destroy(group); else drt_renderer_destroy(handle); }
     Renderer(const Renderer &) = delete;
     Renderer &operator=(const Renderer &) = delete;
 
-    void ResizeBuffer(uint32_t width, uint32_t height) { drt::check(drt_renderer_resize(handle, width, height)); }
-    void Render(Camera *cam, const Scene &scene, float *delta) {
-        drt_settings s = m_RendererSettings.pod();
-        drt::check(drt_renderer_set_settings(handle, &s));
-        drt_camera c = cam->pod();
-        drt::check(drt_renderer_render(handle, &c, scene.handle, delta));
+    void ResizeBuffer(uint32_t width, uint32_t height) {
+        drt::check(group ? drt_group_resize(group, width, height) : drt_renderer_resize(handle, width, height));
     }
+    void Render(Camera *cam, const Scene &scene, float *delta) { RenderBatch(cam, scene, 1, delta); }
     // spp batch: frames getSampleCount() .. +n-1 in one launch, same image as n Render() calls
     void RenderBatch(Camera *cam, const Scene &scene, uint32_t n_frames, float *delta) {
         drt_settings s = m_RendererSettings.pod();
-        drt::check(drt_renderer_set_settings(handle, &s));
         drt_camera c = cam->pod();
-        drt::check(drt_renderer_render_batch(handle, &c, scene.handle, n_frames, delta));
+        if (group) {
+            drt::check(drt_group_set_settings(group, &s));
+            drt::check(drt_group_render_batch(group, &c, scene.handle, n_frames, delta));
+        } else {
+            drt::check(drt_renderer_set_settings(handle, &s));
+            drt::check(drt_renderer_render_batch(handle, &c, scene.handle, n_frames, delta));
+        }
     }
     uint32_t getBufferWidth() const { return drt_renderer_width(handle); }
     uint32_t getBufferHeight() const { return drt_renderer_height(handle); }
     uint32_t getSampleCount() const { return drt_renderer_sample_count(handle); }
-    void resetAccumulationBuffer() { drt::check(drt_renderer_reset(handle)); }
+    void resetAccumulationBuffer() { drt::check(group ? drt_group_reset(group) : drt_renderer_reset(handle)); }
+    int deviceCount() const { return group ? (int)drt_group_size(group) : 1; }
 
     // replaces GLuint& GetRenderTargetImage_name(): RGBA32F, row 0 = bottom, width*height*4 floats
-    void ReadRenderTarget(float *dst) { drt::check(drt_renderer_read_rgba32f(handle, dst, (size_t)getBufferWidth() * drt_renderer_local_rows(handle) * 4)); }
-    void *DeviceRenderTarget() { return drt_renderer_device_rgba(handle); }
+    void ReadRenderTarget(float *dst) {
+        const size_t n = (size_t)getBufferWidth() * getBufferHeight() * 4;
+        drt::check(group ? drt_group_read_rgba32f(group, dst, n) : drt_renderer_read_rgba32f(handle, dst, n));
+    }
+    void *DeviceRenderTarget() { return group ? drt_group_device_rgba(group) : drt_renderer_device_rgba(handle); }
 
     RendererSettings m_RendererSettings;
-    drt_renderer *handle;
+    drt_renderer *handle = nullptr;       // the (first) device's renderer
+    drt_group *group = nullptr;           // set when the renderer spans several devices
 };

@@ -213,6 +213,30 @@ int32_t       drt_renderer_launch_count(const drt_renderer *r);
  * `image` = full width*height float4.  Runs on `hip_stream`. */
 int           drt_assemble_shards(const void *gathered, void *image, uint32_t width, uint32_t height,
                                   uint32_t stripe_rows, uint32_t world, uint32_t padded_rows, void *hip_stream);
+/* ---- several GPUs of one node behind one object (one process, N devices) ------------------------------
+ * Each device renders its 8-row stripes of the frame (drt_renderer_set_shard; seeds use the global pixel index, so the image
+ * is bit-identical to the one-GPU image) on its own stream; the stripes are then gathered into device `devices[0]`'s full
+ * RGBA32F image over RCCL -- grouped ncclSend / ncclRecv, every stripe received at its rows of the image (no assemble
+ * pass), one xGMI link per peer.  RCCL is loaded (dlopen) only when a group of more than one device is created.
+ * Same contract as the renderer otherwise: frame index from 1, no-op at max_samples, blocking render returns wall ms. */
+typedef struct drt_group drt_group;
+drt_group    *drt_group_create(const int32_t *devices, int32_t n_devices);     /* NULL on failure (drt_last_error) */
+void          drt_group_destroy(drt_group *g);
+int32_t       drt_group_size(const drt_group *g);
+drt_renderer *drt_group_renderer(drt_group *g, int32_t index);                /* the device's renderer (settings, counters, kernel info) */
+int           drt_group_resize(drt_group *g, uint32_t width, uint32_t height);
+int           drt_group_set_settings(drt_group *g, const drt_settings *s);
+int           drt_group_reset(drt_group *g);
+int           drt_group_render_batch(drt_group *g, const drt_camera *cam, const drt_scene *scene, uint32_t n_frames, float *delta_ms);
+int           drt_group_render_batch_async(drt_group *g, const drt_camera *cam, const drt_scene *scene, uint32_t n_frames);
+int           drt_group_wait(drt_group *g, float *delta_ms);
+uint32_t      drt_group_sample_count(const drt_group *g);
+void         *drt_group_device_rgba(drt_group *g);                             /* float4[width*height] on devices[0] */
+int           drt_group_read_rgba32f(drt_group *g, float *dst, size_t dst_floats);
+/* Stripe k of `rank` in a `world`-way split: offset in the rank's compact shard, offset in the full image, length -- in floats
+ * of an RGBA32F frame.  Returns 0 when the rank has no k-th stripe.  (What the gather's send / receive offsets are made of.) */
+int           drt_shard_stripe(uint32_t width, uint32_t height, uint32_t stripe_rows, uint32_t rank, uint32_t world, uint32_t k,
+                               uint64_t *src_offset_floats, uint64_t *dst_offset_floats, uint64_t *count_floats);
 /* Self-check of the kernels' reciprocal (device_math.hpp exact_rcp) against IEEE 1.0f/x over all 2^32 float bit patterns. */
 int           drt_debug_check_rcp(int32_t device, uint64_t *mismatches, uint64_t *fast_path_count);
 int           drt_debug_check_sqrt(int32_t device, uint64_t *mismatches, uint64_t *fast_path_count);   /* exact_sqrt vs sqrtf */

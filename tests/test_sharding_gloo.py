@@ -72,3 +72,84 @@ def test_shard_bookkeeping():
         assert sorted(seen.tolist()) == list(range(height))             # a partition of the rows
         for r in range(world):
             assert drt.shard_rows(height, stripe, r, world) == len(shard_row_map(height, stripe, r, world))
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("W,H", [(64, 44), (7, 8), (33, 1), (16, 129)])
+def test_group_gather_offsets_put_every_stripe_in_place(world, W, H):
+    """drt_shard_stripe is what drt_group_render_batch builds its ncclSend / ncclRecv offsets from (csrc/drt_group.cpp): sending
+    every stripe of every rank to its destination offset must rebuild the image, short last stripe included, and a rank's
+    stripes must tile its compact shard exactly (CPU check of the multi-GPU entry point's bookkeeping; worlds 2, 3 and 8)."""
+    rng = np.random.default_rng(W * 1000 + H + world)
+    image = rng.random((H, W, 4), dtype=np.float32)
+    rebuilt = np.full(H * W * 4, np.nan, np.float32)
+    for rank in range(world):
+        rows = [y for y in range(H) if (y // STRIPE) % world == rank]
+        shard = image[rows].reshape(-1)                                 # what the rank's renderer holds (compact)
+        assert len(rows) == drt.shard_rows(H, STRIPE, rank, world)
+        covered, k = 0, 0
+        while True:
+            st = drt.shard_stripe(W, H, STRIPE, rank, world, k)
+            if st is None:
+                break
+            src, dst, cnt = st
+            assert src == covered and cnt > 0                           # stripes tile the shard with no gap
+            rebuilt[dst:dst + cnt] = shard[src:src + cnt]
+            covered += cnt
+            k += 1
+        assert covered == shard.size
+        assert drt.shard_stripe(W, H, STRIPE, rank, world, k + 1) is None
+    assert np.array_equal(bits(rebuilt.reshape(H, W, 4)), bits(image))
+    assert drt.shard_stripe(W, H, 0, 0, world, 0) is None and drt.shard_stripe(W, H, STRIPE, world, world, 0) is None
+
+
+@pytest.mark.gpu
+def test_group_of_one_device_equals_the_single_renderer():
+    """The C ABI's multi-GPU entry point (drt_group_*) with the one device this box has: same frames, same bits as drt_renderer_*,
+    blocking and asynchronous, across a resize; a second batch continues the accumulation."""
+    import dustraytracer_amd as d
+    sc = d.Scene(); sc.loadGLTFmodel(scene_path("cornell_box"))
+    b = d.BVHBuilder(); b.m_TargetLeafPrimitivesCount, b.m_BinCount = 20, 8; b.buildIterative(sc)
+    _, pos, fwd, _ = SCENES["cornell_box"]
+    cam = d.Camera(pos); cam.m_Forward_dir = np.array(fwd, np.float32)
+    g, r = d.RendererGroup([0]), d.Renderer(0)
+    assert g.size() == 1
+    for w, h in ((160, 90), (61, 37)):
+        for x in (g, r):
+            x.m_RendererSettings = d.RendererSettings(ray_bounce_limit=4, max_samples=100)
+            x.ResizeBuffer(w, h)
+            x.resetAccumulationBuffer()
+        g.RenderBatch(cam, sc, 3); r.RenderBatch(cam, sc, 3)
+        assert g.getSampleCount() == r.getSampleCount() == 4
+        assert np.array_equal(bits(g.GetRenderTargetImage()), bits(r.GetRenderTargetImage()))
+        g.RenderBatchAsync(cam, sc, 2); r.RenderBatch(cam, sc, 2)
+        assert g.Wait() >= 0
+        assert np.array_equal(bits(g.GetRenderTargetImage()), bits(r.GetRenderTargetImage()))
+    assert g.kernelInfo().startswith("path_pool")
+    with pytest.raises(d.DrtError):
+        d.RendererGroup([0, 0])                                          # a device twice
+    with pytest.raises(d.DrtError):
+        d.RendererGroup([97])
+
+
+@pytest.mark.gpu
+def test_group_gather_through_rccl_on_one_device(monkeypatch):
+    """DRT_GROUP_FORCE_RCCL=1: the group of one device loads RCCL (dlopen), creates its communicator and moves its stripes with
+    grouped ncclSend / ncclRecv (to itself) at the offsets of drt_shard_stripe -- the plumbing of the N-GPU gather, on this box."""
+    import dustraytracer_amd as d
+    monkeypatch.setenv("DRT_GROUP_FORCE_RCCL", "1")
+    try:
+        g = d.RendererGroup([0])
+    except d.DrtError as e:
+        pytest.skip("RCCL cannot be loaded here: %s" % e)
+    monkeypatch.delenv("DRT_GROUP_FORCE_RCCL")
+    r = d.Renderer(0)
+    sc = d.Scene(); sc.loadGLTFmodel(scene_path("room"))
+    b = d.BVHBuilder(); b.m_TargetLeafPrimitivesCount, b.m_BinCount = 20, 8; b.buildIterative(sc)
+    _, pos, fwd, _ = SCENES["room"]
+    cam = d.Camera(pos); cam.m_Forward_dir = np.array(fwd, np.float32)
+    for x in (g, r):
+        x.m_RendererSettings = d.RendererSettings(ray_bounce_limit=3, max_samples=100)
+        x.ResizeBuffer(200, 61)                                          # 7 full stripes + one of 5 rows
+        x.RenderBatch(cam, sc, 2)
+    assert np.array_equal(bits(g.GetRenderTargetImage()), bits(r.GetRenderTargetImage()))
