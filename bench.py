@@ -58,6 +58,8 @@ def parse_args():
     ap.add_argument("--emulate-shard", default="", help="R/W: render only rank R's stripes of a W-way split on ONE GPU, no gather "
                     "(what one GPU of a W-GPU run computes; for tuning small-shard behaviour on a 1-GPU box)")
     ap.add_argument("--no-roofline-counters", action="store_true", help="skip the counting launch (roofline = null)")
+    ap.add_argument("--group", action="store_true", help="ONE process drives all --gpus devices through the C ABI's drt_group_* (stripes "
+                    "per device, gathered into device 0's image with RCCL send / recv inside the library) instead of one rank per GPU")
     return ap.parse_args()
 
 
@@ -117,10 +119,67 @@ def load_profile(workload):
 VALU_PEAK_GSLOTS = 1024 * 2.4e9 / 2 / 1e9     # 256 CUs x 4 SIMDs, 2.4 GHz, one wave64 add / mul / min / max issues every 2 cycles
 
 
+def main_group(args):
+    """--group: the in-process multi-GPU path (include/drt.h drt_group_*).  Same step, same JSON line; the gather is part of
+    every step (drt_group_wait returns when device 0 holds the whole frame)."""
+    import numpy as np
+    import dustraytracer_amd as drt
+    from tests.scenes import SCENES, scene_path
+    scene_key, W, H, spp, depth = WORKLOADS[args.workload]
+    _, pos, fwd, _ = SCENES[scene_key]
+    scene = drt.Scene()
+    scene.loadGLTFmodel(scene_path(scene_key))
+    builder = drt.BVHBuilder()
+    builder.m_TargetLeafPrimitivesCount, builder.m_BinCount = 20, 8
+    builder.buildIterative(scene)
+    cam = drt.Camera(pos)
+    cam.m_Forward_dir = np.array(fwd, np.float32)
+    groups = [drt.RendererGroup(list(range(args.gpus))) for _ in range(max(1, args.frames_in_flight))]
+    for g in groups:
+        g.m_RendererSettings = drt.RendererSettings(ray_bounce_limit=depth, max_samples=spp + 1)
+        g.ResizeBuffer(W, H)
+    busy = [False] * len(groups)
+
+    def step(i):
+        k = i % len(groups)
+        if busy[k]:
+            groups[k].Wait()
+        groups[k].resetAccumulationBuffer()
+        groups[k].RenderBatchAsync(cam, scene, spp)
+        busy[k] = True
+
+    def drain():
+        for k, g in enumerate(groups):
+            if busy[k]:
+                g.Wait()
+                busy[k] = False
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    drain()
+    elapsed = time.perf_counter() - t0
+    out = {"metric": "Msamples/sec at 1920x1080, 8spp, cornell_box" if args.workload == "cornell_box_1080p_8spp_d8" else "Msamples/sec",
+           "value": round(W * H * spp * args.steps / elapsed / 1e6, 3), "unit": "Msamples/s", "n_gpus": args.gpus, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": args.workload, "scene": SCENES[scene_key][0], "width": W, "height": H, "spp": spp, "depth": depth,
+                      "bvh": "leaf20/bins8", "pose": {"pos": list(pos), "fwd": list(fwd)},
+                      "parallelism": "group: one process, stripes%dx%d, RCCL send/recv into device 0" % (STRIPE_ROWS, args.gpus),
+                      "frames_in_flight": len(groups), "kernel": groups[0].kernelInfo()},
+           "roofline": None}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse_args()
     if args.frames_in_flight <= 0:
         args.frames_in_flight = 2 if args.workload == "room_4k_64spp_d16" else 3
+    if args.group:
+        return main_group(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -651,6 +651,9 @@ bool path_pool_supports(const SceneView &sc, const FrameParams &fp, int bvh_dept
     if (scene_lds_bytes > kLdsSceneBytes || sc.n_tris >= 4095u || bvh_depth > 200) return false;
     if (fp.bounce_limit > 60000) return false;                                            // the bounce index is kept in 16 bits
     if (sc.root_ref == kNoNode) return false;
+    // a pool of at least 256 paths has to fit the CU's LDS next to the scene copy (a very deep tree's stacks may not leave room)
+    const uint32_t stack_entries = (uint32_t)std::max(bvh_depth, 1);
+    if (pool_layout(256u, 256u, stack_entries, pool_scene_bytes(sc), 0u).total > 160u * 1024u) return false;
     return true;
 }
 

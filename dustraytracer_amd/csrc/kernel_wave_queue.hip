@@ -893,7 +893,9 @@ hipError_t launch_wave_queue(const SceneView &sc, const FrameParams &fp, int bvh
     const int stack = std::max(bvh_depth, 1);
     const size_t scene_bytes = wave_queue_scene_lds_bytes(sc);
     static const size_t lds_scene_budget = std::getenv("DRT_LDS_SCENE_KB") ? (size_t)std::atoi(std::getenv("DRT_LDS_SCENE_KB")) * 1024 : kLdsSceneBytes;
-    const bool lds_scene = scene_bytes <= lds_scene_budget;
+    // (a small scene under a degenerate, very deep tree: the stacks of one 256-thread group and the scene copy must fit the
+    // CU's 160 KB together, else the tree is read from HBM and the stacks have the LDS to themselves)
+    const bool lds_scene = scene_bytes <= lds_scene_budget && scene_bytes + (size_t)stack * kThreads * sizeof(StackEntry) <= 160u * 1024u;
     hipError_t e = hipSuccess;                 // (*chunk_counter is zero: drt_capi.cpp hands out zeroed counters)
     static const char *names[2][6] = { { "wave_queue<lean,hbm-scene>", "wave_queue<general,hbm-scene>", "wave_queue<counting,hbm-scene>", "wave_queue<lean+alpha,hbm-scene>",
                                          "wave_queue<lean+sun,hbm-scene>", "wave_queue<lean+alpha+sun,hbm-scene>" },

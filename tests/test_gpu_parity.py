@@ -499,6 +499,20 @@ def test_edge_case_scenes_and_frame_sizes(renderer):
     assert "hbm-scene" in renderer.kernelInfo() and "stack=%d" % sc.bvh_depth in renderer.kernelInfo()
     img, ref = _render_both(renderer, sc, osc, (0.0, 0.5, 9.0), (0, -0.05, -1), 96, 54, 2, ray_bounce_limit=6, enableSunlight=1)
     compare(img, ref, "soup with sun shadows through cut-outs")
+    # (2b) a small scene under a degenerate tree: 62 triangles whose centroids double in x peel off one per level (leaf size 1, two
+    #      bins) -- the scene fits LDS many times over, the traversal stacks of a tree this deep take most of it
+    n = 62
+    cx = (2.0 ** np.arange(n)).astype(np.float32)
+    pos = np.zeros((n, 3, 3), np.float32)
+    pos[:, :, 0] = cx[:, None]
+    pos += (np.float32([[0, -1, -1], [0, 1, -1], [0, 0, 1]]) * 0.4)[None] * cx[:, None, None]
+    nrm = np.tile(np.float32([-1, 0, 0]), (n, 3, 1))
+    sc, osc = _programmatic_pair(pos, nrm, np.zeros((n, 3, 2), np.float32), np.zeros(n, np.int32), [((0.7, 0.6, 0.5), -1)], [], 1, 2)
+    assert 32 < sc.bvh_depth <= 64
+    for kw in ({}, {"enableSunlight": 1}):
+        img, ref = _render_both(renderer, sc, osc, (-3.0, 0.1, 0.2), (1.0, 0.02, -0.03), 64, 36, 2, ray_bounce_limit=3, **kw)
+        compare(img, ref, "degenerate %d-level tree %r (%s)" % (sc.bvh_depth, kw, renderer.kernelInfo()))
+        assert "stack=%d" % sc.bvh_depth in renderer.kernelInfo()
     # (3) long paths: the closed cornell box with 32 bounces
     sc, osc = make_pair("cornell_box")
     cam, ocam = cameras("cornell_box")
