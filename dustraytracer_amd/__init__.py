@@ -188,6 +188,7 @@ _sig("drt_scene_add_material", C.c_int, _P, C.POINTER(C.c_float), C.c_int32)
 _sig("drt_scene_add_texture", C.c_int, _P, _P, C.c_int32, C.c_int32, C.c_int32)
 _sig("drt_scene_build_bvh", C.c_int, _P, C.c_int32, C.c_int32)
 _sig("drt_scene_validate", C.c_int, _P)
+_sig("drt_scene_build_bvh_recursive", C.c_int, _P, C.c_int32, C.c_int32)
 _sig("drt_scene_build_bvh_device", C.c_int, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float))
 for _n in ("triangle", "node", "material", "texture", "mesh"):
     _sig("drt_scene_%s_count" % _n, C.c_int32, _P)
@@ -368,7 +369,11 @@ class BVHBuilder:
             _check(_lib.drt_scene_build_bvh(scene._h, self.m_TargetLeafPrimitivesCount, self.m_BinCount))
         return scene
 
-    build = buildIterative      # BVHBuilder.cu:100-173 produces the same tree through recursion
+    def build(self, scene):
+        """BVHBuilder::build (BVHBuilder.cu:100-173): the same tree and triangle order through recursion; the node array comes in
+        the recursion's order (children after both of their subtrees, root last), as drt_scene_get_nodes then returns it."""
+        _check(_lib.drt_scene_build_bvh_recursive(scene._h, self.m_TargetLeafPrimitivesCount, self.m_BinCount))
+        return scene
 
 
 def shard_stripe(width, height, stripe_rows, rank, world, k):

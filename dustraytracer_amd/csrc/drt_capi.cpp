@@ -232,6 +232,11 @@ int drt_scene_build_bvh(drt_scene *s, int32_t target_leaf_prims, int32_t bin_cou
     try { s->host.build_bvh(target_leaf_prims, bin_count); return DRT_OK; } catch (...) { return from_exception(); }
 }
 
+int drt_scene_build_bvh_recursive(drt_scene *s, int32_t target_leaf_prims, int32_t bin_count) {
+    if (!s) return fail(DRT_ERR_INVALID, "null scene");
+    try { s->host.build_bvh(target_leaf_prims, bin_count); s->host.renumber_as_recursive_build(); return DRT_OK; } catch (...) { return from_exception(); }
+}
+
 int drt_scene_build_bvh_device(drt_scene *s, int32_t target_leaf_prims, int32_t bin_count, int32_t device, float *build_ms) {
     if (!s) return fail(DRT_ERR_INVALID, "null scene");
     if (build_ms) *build_ms = 0.f;

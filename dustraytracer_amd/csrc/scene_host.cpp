@@ -707,6 +707,37 @@ int32_t HostScene::bvh_depth() const {
 // ---------------------------------------------------------------------------------------------
 // Device packing
 // ---------------------------------------------------------------------------------------------
+void HostScene::renumber_as_recursive_build() {
+    if (nodes.size() < 2) return;
+    const size_t n = nodes.size();
+    std::vector<int32_t> order;                     // old indices in the order recursiveBuild appends them
+    order.reserve(n);
+    // iterative post-order: (node, state) -- state 0 = descend into child1, 1 = into child2, 2 = append both children
+    std::vector<std::pair<int32_t, int>> st;
+    st.emplace_back((int32_t)n - 1, 0);
+    while (!st.empty()) {
+        auto &top = st.back();
+        const drt_bvh_node &nd = nodes[(size_t)top.first];
+        if (nd.is_leaf) { st.pop_back(); continue; }
+        if (top.second == 0) { top.second = 1; st.emplace_back(nd.child1, 0); }
+        else if (top.second == 1) { top.second = 2; st.emplace_back(nd.child2, 0); }
+        else { order.push_back(nd.child1); order.push_back(nd.child2); st.pop_back(); }
+    }
+    order.push_back((int32_t)n - 1);
+    if (order.size() != n) throw BvhError("BVH is not a binary tree rooted at its last node");
+    std::vector<int32_t> new_index(n, -1);
+    for (size_t i = 0; i < n; i++) new_index[(size_t)order[i]] = (int32_t)i;
+    std::vector<drt_bvh_node> out(n);
+    for (size_t i = 0; i < n; i++) {
+        drt_bvh_node nd = nodes[(size_t)order[i]];
+        if (!nd.is_leaf) { nd.child1 = new_index[(size_t)nd.child1]; nd.child2 = new_index[(size_t)nd.child2]; }
+        out[i] = nd;
+    }
+    if (!out.back().is_leaf) out.back().prim_start = -1;          // BVHBuilder.cu:112-118: only a leaf root gets primitive_start_idx = 0
+    nodes.swap(out);
+    revision = next_revision();
+}
+
 PackedScene HostScene::pack() const {
     if (nodes.empty()) throw std::invalid_argument("scene has no BVH: call build_bvh first (EditorLayer.cpp:52-55)");
     PackedScene ps;

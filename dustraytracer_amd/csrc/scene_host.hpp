@@ -44,6 +44,10 @@ public:
     void load_gltf(const char *path, bool strict = false);        // throws std::runtime_error / UnsupportedError
     void set_geometry(const float *pos, const float *nrm, const float *uv, const int32_t *mat, int32_t n_tris);
     void build_bvh(int32_t target_leaf_prims, int32_t bin_count);   // throws BvhError when the reference would hang
+    // BVHBuilder::build (BVHBuilder.cu:100-173): the same partitions, hence the same tree and triangle order, with the node
+    // array in the recursion's order (a node's two children follow both of their subtrees; root last; a split root keeps
+    // primitive_start_idx = -1).  Call after build_bvh / build_bvh_on_device.
+    void renumber_as_recursive_build();
     // The same tree built on a GPU (kernel_bvh_build.hip); returns the device time in ms.  Throws DeviceError without one.
     float build_bvh_on_device(int32_t target_leaf_prims, int32_t bin_count, int device);
     int32_t bvh_depth() const;

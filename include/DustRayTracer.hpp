@@ -176,14 +176,23 @@ public:
             drt::check(drt_scene_build_bvh(scene.handle, m_TargetLeafPrimitivesCount, m_BinCount));
         scene.d_BVHTreeRoot = scene.handle;
     }
-    void build(Scene &scene) { buildIterative(scene); }                   // BVHBuilder.cu:100-173: same tree via recursion
+    // BVHBuilder.cu:100-173: the same tree through recursion -- same nodes, same triangle order, node ARRAY in the recursion's
+    // order (children after both of their subtrees); always on the host
+    void build(Scene &scene) {
+        drt::check(drt_scene_build_bvh_recursive(scene.handle, m_TargetLeafPrimitivesCount, m_BinCount));
+        scene.d_BVHTreeRoot = scene.handle;
+    }
     // the reference's spelling (EditorLayer.cpp:55): both arguments name parts of one scene; returns the root token
     const void *buildIterative(Scene::Part &primitives, Scene::Part &nodes) {
         if (primitives.scene != nodes.scene) throw drt::Error(DRT_ERR_INVALID, "primitives and nodes of different scenes");
         buildIterative(*primitives.scene);
         return primitives.scene->d_BVHTreeRoot;
     }
-    const void *build(Scene::Part &primitives, Scene::Part &nodes) { return buildIterative(primitives, nodes); }
+    const void *build(Scene::Part &primitives, Scene::Part &nodes) {
+        if (primitives.scene != nodes.scene) throw drt::Error(DRT_ERR_INVALID, "primitives and nodes of different scenes");
+        build(*primitives.scene);
+        return primitives.scene->d_BVHTreeRoot;
+    }
 };
 
 // Core/Renderer.hpp:14-47.  Renderer(device) renders on one GPU; Renderer({0, 1, ..., 7}) renders on several GPUs of the

@@ -143,6 +143,9 @@ int        drt_scene_add_texture(drt_scene *s, const uint8_t *texels, int32_t wi
 int        drt_scene_build_bvh(drt_scene *s, int32_t target_leaf_prims, int32_t bin_count);  /* BVHBuilder::buildIterative */
 /* The same build run on GPU `device`: identical nodes, node order and triangle order -- a bound that
  * is a zero may carry the other sign.  build_ms (may be NULL) receives the device time.  DRT_ERR_DEVICE without a GPU. */
+/* BVHBuilder::build (BVH/BVHBuilder.cu:100-173): the same tree and triangle order as drt_scene_build_bvh, with the node array in
+ * the order the reference's recursion appends it (a node's two children after both of their subtrees, root last). */
+int        drt_scene_build_bvh_recursive(drt_scene *s, int32_t target_leaf_prims, int32_t bin_count);
 int        drt_scene_build_bvh_device(drt_scene *s, int32_t target_leaf_prims, int32_t bin_count, int32_t device, float *build_ms);
 /* Checks what the kernels index without checks: every triangle's material id, every material's texture index, the BVH's
  * child and triangle ranges.  DRT_ERR_INVALID names the first offender; rendering runs the same check before uploading. */

@@ -79,6 +79,8 @@ def lib():
         L.o_pcg_hash.argtypes = [C.c_uint32]
         L.o_bvh_build.restype = C.c_int32
         L.o_bvh_build.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
+        L.o_bvh_build_recursive.restype = C.c_int32
+        L.o_bvh_build_recursive.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
         L.o_build_triangles.restype = None
         L.o_build_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         L.o_render.restype = None
@@ -154,11 +156,13 @@ class Scene:
         sc.meshes = d["meshes"]
         return sc
 
-    def build_bvh(self, leaf=20, bins=8):
-        """BVHBuilder{m_TargetLeafPrimitivesCount=leaf, m_BinCount=bins}.buildIterative (EditorLayer.cpp:52-55)."""
+    def build_bvh(self, leaf=20, bins=8, recursive=False):
+        """BVHBuilder{m_TargetLeafPrimitivesCount=leaf, m_BinCount=bins}.buildIterative (EditorLayer.cpp:52-55); recursive=True:
+        BVHBuilder::build (BVHBuilder.cu:100-173), the same tree with the nodes in the recursion's order."""
         cap = 2 * len(self.tris) + 2
         nodes = np.zeros(cap, NODE_DTYPE)
-        n = lib().o_bvh_build(_ptr(self.tris), len(self.tris), leaf, bins, _ptr(nodes), cap)
+        fn = lib().o_bvh_build_recursive if recursive else lib().o_bvh_build
+        n = fn(_ptr(self.tris), len(self.tris), leaf, bins, _ptr(nodes), cap)
         if n < 0:
             raise RuntimeError("o_bvh_build failed: %d" % n)
         self.nodes = nodes[:n].copy()

@@ -868,6 +868,54 @@ int32_t o_bvh_build(o_triangle *tris, int32_t n_tris, int32_t leaf_target, int32
     return count;
 }
 
+/* BVHBuilder.cu:149-173 recursiveBuild: the node's two children are appended after BOTH subtrees (post-order). */
+static int recursive_build(o_bvh_node *node, o_triangle *tris, int32_t leaf_target, int32_t bin_count, o_bvh_node *nodes, int32_t cap,
+                           int32_t *count, int32_t *lidx, int32_t *ridx, int depth)
+{
+    if (node->prim_count <= leaf_target) { node->child1 = node->child2 = -1; node->is_leaf = 1; return 0; }     /* :153-158 */
+    if (depth > 4096) return -1;
+    o_bvh_node l, r; init_node(&l); init_node(&r);
+    make_partition(tris, node->prim_start, node->prim_start + node->prim_count, bin_count, &l, &r, lidx, ridx);    /* :164 */
+    if (l.prim_count == 0 || r.prim_count == 0) return -2;                 /* the reference would recurse forever */
+    int rc = recursive_build(&l, tris, leaf_target, bin_count, nodes, cap, count, lidx, ridx, depth + 1);         /* :166 */
+    if (rc < 0) return rc;
+    rc = recursive_build(&r, tris, leaf_target, bin_count, nodes, cap, count, lidx, ridx, depth + 1);             /* :167 */
+    if (rc < 0) return rc;
+    if (*count + 2 > cap) return -1;
+    nodes[*count] = l; node->child1 = (*count)++;                                                                  /* :169-170 */
+    nodes[*count] = r; node->child2 = (*count)++;                                                                  /* :172-173 */
+    return 0;
+}
+
+/* BVHBuilder.cu:100-147 BVHBuilder::build: the same partitions as buildIterative, nodes numbered by the recursion. */
+int32_t o_bvh_build_recursive(o_triangle *tris, int32_t n_tris, int32_t leaf_target, int32_t bin_count,
+                              o_bvh_node *nodes, int32_t cap)
+{
+    if (cap < 1) return -1;
+    o_bvh_node root; init_node(&root);
+    f3 mn;
+    f3 ext = absolute_extent(tris, NULL, 0, n_tris, &mn);                                   /* :107-110 */
+    set_bounds(&root, mn, ext);
+    root.prim_count = n_tris;                              /* :112 (primitive_start_idx keeps its default, -1, unless the root is a leaf) */
+    if (n_tris <= leaf_target) { root.is_leaf = 1; root.prim_start = 0; nodes[0] = root; return 1; }       /* :115-124 */
+    int32_t *lidx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_tris + 1));
+    int32_t *ridx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_tris + 1));
+    int32_t count = 0;
+    int rc = 0;
+    o_bvh_node l, r; init_node(&l); init_node(&r);
+    make_partition(tris, 0, n_tris, bin_count, &l, &r, lidx, ridx);                         /* :129-130 */
+    if (l.prim_count == 0 || r.prim_count == 0) rc = -2;
+    if (rc == 0) rc = recursive_build(&l, tris, leaf_target, bin_count, nodes, cap - 3, &count, lidx, ridx, 1);   /* :132 */
+    if (rc == 0) rc = recursive_build(&r, tris, leaf_target, bin_count, nodes, cap - 3, &count, lidx, ridx, 1);   /* :133 */
+    free(lidx); free(ridx);
+    if (rc < 0) return rc;
+    if (count + 3 > cap) return -1;
+    nodes[count] = l; root.child1 = count++;                                                /* :135-136 */
+    nodes[count] = r; root.child2 = count++;                                                /* :138-139 */
+    nodes[count++] = root;                                                                  /* :142 */
+    return count;
+}
+
 /* ================= KAT entry points ================= */
 
 void o_kat_random_float(uint32_t seed, int32_t n, float *out, uint32_t *seed_out)

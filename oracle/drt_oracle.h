@@ -124,6 +124,9 @@ void o_build_triangles(const float *pos, const float *nrm, const float *uv,
  * (-2 = builder would not terminate: degenerate partition). */
 int32_t o_bvh_build(o_triangle *tris, int32_t n_tris, int32_t leaf_target,
                     int32_t bin_count, o_bvh_node *nodes_out, int32_t nodes_cap);
+/* BVHBuilder::build (BVHBuilder.cu:100-173): same tree, nodes in the recursion's order (children after both subtrees, root last) */
+int32_t o_bvh_build_recursive(o_triangle *tris, int32_t n_tris, int32_t leaf_target, int32_t bin_count,
+                              o_bvh_node *nodes, int32_t cap);
 
 /* ---- render (K1-K14) ---- */
 

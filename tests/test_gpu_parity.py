@@ -678,3 +678,24 @@ def test_path_pool_falls_back_where_it_does_not_apply():
         assert r.kernelInfo().startswith("wave_queue"), (name, kw, r.kernelInfo())
         ref, _, _ = oracle.render(osc, ocam, o, 96, 54, 1, 2)
         compare(r.GetRenderTargetImage(), ref, "%s %r" % (name, kw))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell_box", "suzanne_plane"])
+def test_recursive_build_order_renders_the_same_image(renderer, name):
+    """BVHBuilder::build numbers the nodes differently from buildIterative (BVHBuilder.cu:100-173 vs :11-92); the tree is the same
+    tree, so every traversal visits the same boxes and triangles in the same order: same image, bit for bit."""
+    sc = drt.Scene(); sc.loadGLTFmodel(scene_path(name))
+    b = drt.BVHBuilder(); b.m_TargetLeafPrimitivesCount, b.m_BinCount = 20, 8
+    b.build(sc)
+    osc = oracle.Scene.load_glb(scene_path(name)).build_bvh(20, 8, recursive=True)
+    cam, ocam = cameras(name)
+    s, o = settings_pair(ray_bounce_limit=4)
+    renderer.m_RendererSettings = s
+    renderer.ResizeBuffer(128, 72)
+    renderer.resetAccumulationBuffer()
+    renderer.RenderBatch(cam, sc, 2)
+    ref, _, _ = oracle.render(osc, ocam, o, 128, 72, 1, 2)
+    compare(renderer.GetRenderTargetImage(), ref, "recursive build order, oracle with the same order")
+    ref2, _, _ = oracle.render(oracle.Scene.load_glb(scene_path(name)).build_bvh(20, 8), ocam, o, 128, 72, 1, 2)
+    assert np.array_equal(bits(ref), bits(ref2))

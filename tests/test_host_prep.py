@@ -422,3 +422,32 @@ def test_strict_loading_of_the_reference_scenes_with_transforms():
     ca = np.sort(a.m_PrimitivesBuffer["centroid"].view([("x", "<f4"), ("y", "<f4"), ("z", "<f4")]).reshape(-1), order=["x", "y", "z"])
     cb = np.sort(b.m_PrimitivesBuffer["centroid"].view([("x", "<f4"), ("y", "<f4"), ("z", "<f4")]).reshape(-1), order=["x", "y", "z"])
     assert len(ca) == len(cb) == 542
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "room", "suzanne_plane", "dense_monkey", "bvh_split_test", "cs16_dust"])
+@pytest.mark.parametrize("leaf,bins", [(20, 8), (6, 8), (12, 4)])
+def test_recursive_build_numbers_the_nodes_like_the_reference_recursion(name, leaf, bins):
+    """BVHBuilder::build (BVHBuilder.cu:100-173) makes the partitions of buildIterative but appends a node's two children after
+    BOTH of their subtrees.  The product renumbers its iterative build; the oracle restates the recursion itself: the node arrays
+    must be equal bit for bit, the triangle order equal to the iterative build's, and the tree the same tree."""
+    a = drt.Scene(); a.loadGLTFmodel(scene_path(name))
+    b = drt.Scene(); b.loadGLTFmodel(scene_path(name))
+    bld = drt.BVHBuilder(); bld.m_TargetLeafPrimitivesCount, bld.m_BinCount = leaf, bins
+    bld.buildIterative(a); bld.build(b)
+    osc = oracle.Scene.load_glb(scene_path(name)).build_bvh(leaf, bins, recursive=True)
+    na, nb = a.m_BVHNodes, b.m_BVHNodes
+    assert len(nb) == len(na) == len(osc.nodes)
+    assert np.array_equal(a.m_PrimitivesBuffer.view(np.uint8), b.m_PrimitivesBuffer.view(np.uint8))
+    for f in ("is_leaf", "bmin", "bmax", "child1", "child2", "prim_count", "prim_start"):
+        assert np.array_equal(np.asarray(nb[f]), np.asarray(osc.nodes[f])), f
+    b.validate()
+    if len(nb) > 1:
+        assert not np.array_equal(np.asarray(na["child1"]), np.asarray(nb["child1"])) or len(nb) == 3      # a different order, really
+        assert nb[-1]["prim_start"] == -1 and na[-1]["prim_start"] == 0
+
+    def shape(nodes, i):                                # the tree as nested tuples of leaf ranges: independent of the numbering
+        n = nodes[i]
+        return (int(n["prim_start"]), int(n["prim_count"])) if n["is_leaf"] else (shape(nodes, int(n["child1"])), shape(nodes, int(n["child2"])))
+    import sys
+    sys.setrecursionlimit(10000)
+    assert shape(na, len(na) - 1) == shape(nb, len(nb) - 1)
