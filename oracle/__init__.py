@@ -292,6 +292,27 @@ def kat_surface_area(boxes6, counts):
     return out
 
 
+def kat_surrounds(min_max_x):
+    d = np.ascontiguousarray(_f32(min_max_x).reshape(-1, 3))
+    out = np.zeros(len(d), np.int32)
+    lib().o_kat_surrounds(_ptr(d), C.c_int32(len(d)), _ptr(out))
+    return out
+
+
+def kat_miss(rays6, color3):
+    d = np.ascontiguousarray(np.concatenate([_f32(rays6).reshape(-1, 6), _f32(color3).reshape(-1, 3)], axis=1))
+    out, flags = np.zeros((len(d), 4), np.float32), np.zeros((len(d), 2), np.int32)
+    lib().o_kat_miss(_ptr(d), C.c_int32(len(d)), _ptr(out), _ptr(flags))
+    return out[:, :3].copy(), out[:, 3].copy(), flags[:, 0].copy(), flags[:, 1].copy()
+
+
+def kat_bounds_centroid(boxes6):
+    d = np.ascontiguousarray(_f32(boxes6).reshape(-1, 6))
+    out = np.zeros((len(d), 3), np.float32)
+    lib().o_kat_bounds_centroid(_ptr(d), C.c_int32(len(d)), _ptr(out))
+    return out
+
+
 def kat_closest_hit(rays6, t, face_n3):
     data = np.ascontiguousarray(np.concatenate([_f32(rays6).reshape(-1, 6), _f32(t).reshape(-1, 1), _f32(face_n3).reshape(-1, 3)], axis=1))
     n = len(data)

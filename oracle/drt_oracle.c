@@ -241,6 +241,11 @@ typedef struct {
 
 #define STACK_SIZE 64     /* BVH/BVHTraversal.cuh:17 */
 
+/* Interval::surrounds (Interval.cuh:24-26) */
+static int interval_surrounds(float imin, float imax, float x) { return imin < x && x < imax; }
+/* Bounds3f::getCentroid (Bounds.cu:12-15) */
+static f3 bounds_centroid(f3 pmin, f3 pmax) { return add3(scale3l(0.5f, pmin), scale3l(0.5f, pmax)); }
+
 /* ---- BVH/BVHTraversal.cuh:14-73 ---- */
 static void traverse_bvh(const ray_t *ray, int root, hit_payload *closest, const o_scene *sc, o_counters *cnt)
 {
@@ -257,7 +262,7 @@ static void traverse_bvh(const ray_t *ray, int root, hit_payload *closest, const
         const o_bvh_node *node = &sc->nodes[idx_stack[--sp]];
         float node_dist = dist_stack[sp];
         trace('N');
-        if (!(interval_min < node_dist && node_dist < interval_max)) continue;           /* :38 */
+        if (!interval_surrounds(interval_min, interval_max, node_dist)) continue;        /* :38 ray.interval.surrounds(current_node_hitdist) */
         if (closest->prim != NULL && closest->t < node_dist) continue;                   /* :41 */
         closest->color = add3(closest->color, scale3(v3(1, 1, 1), 0.05f));               /* :43 */
         if (cnt) cnt->node_visits++;
@@ -969,6 +974,30 @@ void o_kat_intersect(const float *rays6, const float *tris9, int32_t n, float *o
         out4[4 * i] = h.t; out4[4 * i + 1] = h.uvw.x; out4[4 * i + 2] = h.uvw.y; out4[4 * i + 3] = h.uvw.z;
         hit[i] = h.hit;
     }
+}
+
+void o_kat_surrounds(const float *min_max_x, int32_t n, int32_t *out)
+{
+    for (int32_t i = 0; i < n; i++) out[i] = interval_surrounds(min_max_x[3 * i], min_max_x[3 * i + 1], min_max_x[3 * i + 2]);
+}
+
+/* Miss (Shaders/Miss.cuh:2-6): a default HitPayload (HitPayload.cuh:8-20) carrying the debug colour; what trace_ray returns
+   when the traversal found nothing.  out per case: colour3, hit_distance, has_prim, front_face. */
+void o_kat_miss(const float *rays6_color3, int32_t n, float *out4, int32_t *flags2)
+{
+    for (int32_t i = 0; i < n; i++) {
+        hit_payload p;
+        memset(&p, 0, sizeof p);
+        p.prim = NULL; p.t = -1;                             /* HitPayload.cuh:12,16 defaults */
+        p.color = ld3(&rays6_color3[9 * i + 6]);             /* Miss.cuh:4 */
+        st3(&out4[4 * i], p.color); out4[4 * i + 3] = p.t;
+        flags2[2 * i] = p.prim != NULL; flags2[2 * i + 1] = 1;   /* front_face default: true (HitPayload.cuh:10) */
+    }
+}
+
+void o_kat_bounds_centroid(const float *boxes6, int32_t n, float *out3)
+{
+    for (int32_t i = 0; i < n; i++) st3(&out3[3 * i], bounds_centroid(ld3(&boxes6[6 * i]), ld3(&boxes6[6 * i + 3])));
 }
 
 void o_kat_surface_area(const float *boxes6, const int32_t *counts, int32_t n, float *out)

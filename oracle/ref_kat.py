@@ -133,3 +133,20 @@ def texpixel(texels, uv2):
 
 def texalpha(texels, uv2):
     return _tex("texalpha", texels, uv2)
+
+
+def surrounds(min_max_x):
+    """Interval(min, max).surrounds(x) for n x (min, max, x)"""
+    return np.frombuffer(_run("surrounds", np.asarray(min_max_x, "<f4").reshape(-1, 3).tobytes()), "<i4").copy()
+
+
+def miss(rays6, color3):
+    """Miss(ray, colour) -> (colour3, hit_distance, has_prim, front_face)"""
+    data = np.concatenate([np.asarray(rays6, "<f4").reshape(-1, 6), np.asarray(color3, "<f4").reshape(-1, 3)], axis=1)
+    rec = np.dtype([("color", "<f4", 3), ("t", "<f4"), ("has_prim", "<i4"), ("front", "<i4")])
+    out = np.frombuffer(_run("miss", np.ascontiguousarray(data).tobytes()), rec)
+    return out["color"].copy(), out["t"].copy(), out["has_prim"].copy(), out["front"].copy()
+
+
+def boundscentroid(boxes6):
+    return np.frombuffer(_run("boundscentroid", np.asarray(boxes6, "<f4").reshape(-1, 6).tobytes()), "<f4").reshape(-1, 3).copy()

@@ -5,7 +5,7 @@
 // _ref/ref_kat): Core/Bounds.cu, Core/CudaMath/Random.cu,
 // Core/Kernel/Shaders/Intersection.cu, Core/Scene/Camera.cu,
 // Core/Scene/Texture.cu, Core/Interval.cu, and the header-only
-// Core/Kernel/Shaders/ClosestHit.cuh.  Headers come from the image: the
+// Core/Kernel/Shaders/ClosestHit.cuh, Core/Kernel/Shaders/Miss.cuh, Core/Interval.cuh.  Headers come from the image: the
 // CUDA toolkit headers bundled with triton, glm and stb_image vendored by the
 // reference.  No stand-in headers or libraries are written; the few CUDA runtime
 // symbols referenced by code paths we never call stay unresolved.
@@ -20,6 +20,8 @@
 #include "Core/Scene/Triangle.cuh"
 #include "Core/HitPayload.cuh"
 #include "Core/Kernel/Shaders/ClosestHit.cuh"
+#include "Core/Kernel/Shaders/Miss.cuh"
+#include "Core/Interval.cuh"
 #include "Core/BVH/BVHNode.cuh"
 #include "Core/Scene/Material.cuh"
 #include "Core/Scene/Mesh.cuh"
@@ -177,6 +179,22 @@ int main(int argc, char **argv)
             node.m_BoundingBox = Bounds3f(make_float3(fin[i], fin[i + 1], fin[i + 2]), make_float3(fin[i + 3], fin[i + 4], fin[i + 5]));
             node.primitives_count = (int)uin[i + 6];
             out.put(node.getSurfaceArea());
+        }
+    } else if (fn == "surrounds") {                      // Interval::surrounds (Interval.cuh:24-26); in: n x (min, max, x) -> out: i32[n]
+        for (size_t i = 0; i + 3 <= in.size() / 4; i += 3) {
+            Interval iv(fin[i], fin[i + 1]);
+            out.put((int32_t)iv.surrounds(fin[i + 2]));
+        }
+    } else if (fn == "miss") {                           // Miss (Shaders/Miss.cuh:2-6); in: n x (orig3, dir3, color3) -> out: n x (color3, hit_distance, i32 has_prim, i32 front_face)
+        for (size_t i = 0; i + 9 <= in.size() / 4; i += 9) {
+            Ray r(make_float3(fin[i], fin[i + 1], fin[i + 2]), make_float3(fin[i + 3], fin[i + 4], fin[i + 5]));
+            HitPayload p = Miss(r, make_float3(fin[i + 6], fin[i + 7], fin[i + 8]));
+            out.put3(p.color); out.put(p.hit_distance); out.put((int32_t)(p.primitiveptr != nullptr)); out.put((int32_t)p.front_face);
+        }
+    } else if (fn == "boundscentroid") {                 // Bounds3f::getCentroid (Bounds.cu:12-15); in: n x (min3, max3) -> out: n x centroid3
+        for (size_t i = 0; i + 6 <= in.size() / 4; i += 6) {
+            Bounds3f b(make_float3(fin[i], fin[i + 1], fin[i + 2]), make_float3(fin[i + 3], fin[i + 4], fin[i + 5]));
+            out.put3(b.getCentroid());
         }
     } else if (fn == "stbload") {                        // Texture.cu:21-30: in: an image file's bytes -> out: i32 w, h, comps, then the texels
         int w = 0, h = 0, n = 0;

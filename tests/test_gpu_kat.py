@@ -96,3 +96,46 @@ def test_rng_hash_has_short_cycles_and_the_guard_terminates():
     assert tries.max() == 1024, "expected at least one start on a short cycle that never accepts (the reference would hang)"
     stuck = tries == 1024
     assert np.isfinite(vec[stuck]).all() and np.allclose(np.linalg.norm(vec[stuck].astype(np.float64), axis=1), 1.0, atol=1e-6)
+
+
+@pytest.mark.parametrize("kernel", ["path_pool", "wave_queue", "pixel_walk"])
+def test_equal_distances_and_equal_hits_resolve_as_in_the_reference_on_the_device(kernel):
+    """Device side of the hand-derived traversal KAT (tests/test_oracle_kat.py tie_scene): child boxes entered at the same
+    distance, triangles hit at the same t; BVHTraversal.cuh:51,63-70 make the triangle of child 1 win.  A camera with a zero
+    field of view sends the same exact ray through every pixel, whatever the jitter.  Debug view (general wave_queue kernel /
+    pixel_walk) shows the winner's albedo; the lean kernels (path_pool, wave_queue lean) show it through one sky bounce."""
+    import os
+    import oracle
+    from tests.test_oracle_kat import tie_scene, tie_winner_albedo
+    from tests.test_gpu_parity import _programmatic_pair, compare
+    pos, nrm, uv, mat, materials = tie_scene()
+    sc, osc = _programmatic_pair(pos, nrm, uv, mat, materials, [], 1, 8)
+    want = tie_winner_albedo(sc.m_BVHNodes, sc.m_PrimitivesBuffer["material"], materials)
+    assert np.array_equal(want, tie_winner_albedo(osc.nodes, osc.tris["material"], materials))
+    old = os.environ.get("DRT_KERNEL")
+    os.environ["DRT_KERNEL"] = kernel
+    try:
+        r = drt.Renderer(0)
+    finally:
+        if old is None: os.environ.pop("DRT_KERNEL", None)
+        else: os.environ["DRT_KERNEL"] = old
+    cam = drt.Camera((-0.5, -0.5, 5.0)); cam.m_Forward_dir = np.float32([0, 0, -1]); cam.vfov_rad = 0.0
+    ocam = oracle.default_camera(position=(-0.5, -0.5, 5.0), forward=(0, 0, -1), vfov_rad=0.0)
+    r.ResizeBuffer(8, 8)
+    # debug albedo view: the winner's colour itself
+    r.m_RendererSettings = drt.RendererSettings(RenderMode=1, DebugMode=0, ray_bounce_limit=0, tone_mapping=0, gamma_correction=0)
+    r.RenderBatch(cam, sc, 1)
+    img = r.GetRenderTargetImage()
+    assert np.array_equal(img[..., :3], np.broadcast_to(want, (8, 8, 3))), (kernel, r.kernelInfo(), img[0, 0])
+    ref, _, _ = oracle.render(osc, ocam, oracle.default_settings(render_mode=1, debug_mode=0, ray_bounce_limit=0, tone_mapping=0, gamma_correction=0), 8, 8, 1, 1)
+    compare(img, ref, "tie, debug view, " + r.kernelInfo())
+    # normal view, one bounce: the path leaves towards the sky with the winner's albedo as throughput
+    r.m_RendererSettings = drt.RendererSettings(ray_bounce_limit=1, tone_mapping=0, gamma_correction=0)
+    r.resetAccumulationBuffer()
+    r.RenderBatch(cam, sc, 1)
+    img = r.GetRenderTargetImage()
+    assert r.kernelInfo().startswith(kernel), r.kernelInfo()
+    loser = 1.0 - want
+    assert (img[..., :3] * loser).max() == 0 and (img[..., :3] * want).max() > 0, (kernel, img[0, 0])
+    ref, _, _ = oracle.render(osc, ocam, oracle.default_settings(ray_bounce_limit=1, tone_mapping=0, gamma_correction=0), 8, 8, 1, 1)
+    compare(img, ref, "tie, one bounce, " + r.kernelInfo())

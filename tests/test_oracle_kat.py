@@ -199,3 +199,64 @@ def test_work_per_sample_matches_the_figures_measured_on_the_reference_sources(n
     got = (d["rays"] / n, d["node_visits"] / n, d["inner_visits"] / n, d["tri_tests"] / n)
     for g, w in zip(got, want):
         assert abs(g - w) <= 0.015 * w + 0.006, (got, want)
+
+
+def test_remaining_reference_leaf_functions(kat_golden):
+    """tests/golden/kat_ref2.npz (tests/golden/make_kat_golden2.py): Interval::surrounds, Miss and Bounds3f::getCentroid from the
+    reference's own sources compiled here -- the last of its functions that build without thrust."""
+    import os
+    from tests.scenes import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "kat_ref2.npz"))
+    assert np.array_equal(oracle.kat_surrounds(g["iv"]), g["surrounds"])
+    assert g["surrounds"][:8].tolist() == [0, 0, 1, 1, 0, 0, 0, 0]          # (-1, FLT_MAX) around -1, FLT_MAX, 0, -0, inf, -inf, NaN, < -1
+    col, t, has_prim, front = oracle.kat_miss(g["miss_rays"], g["miss_color"])
+    assert np.array_equal(bits(col), bits(g["miss_out_color"])) and np.array_equal(bits(t), bits(g["miss_t"]))
+    assert np.array_equal(has_prim, g["miss_has_prim"]) and np.array_equal(front, g["miss_front"]) and not has_prim.any() and (t == -1).all()
+    assert np.array_equal(bits(oracle.kat_bounds_centroid(g["boxes"])), bits(g["boundscentroid"]))
+    from oracle import ref_kat as rk
+    if rk.available():                                       # build container: the reference binary itself, fresh inputs
+        rng = np.random.default_rng(11)
+        iv = rng.normal(size=(5000, 3)).astype(np.float32)
+        assert np.array_equal(oracle.kat_surrounds(iv), rk.surrounds(iv))
+        boxes = rng.normal(size=(5000, 6)).astype(np.float32) * np.float32(1e30)
+        assert np.array_equal(bits(oracle.kat_bounds_centroid(boxes)), bits(rk.boundscentroid(boxes)))
+
+
+def tie_scene():
+    """Two coplanar triangles in two leaves whose boxes a straight-down ray enters at the same distance and which it hits at
+    the same t -- every number dyadic, so 'the same' is exact:  ray o = (-0.5, -0.5, 5), d = (0, 0, -1);
+    A = (-2,-2,.5) (2,-2,.5) (-2,2,.5): det 16, t = 72/16 = 4.5;  B = (-4,-4,.5) (4,-4,.5) (-4,4,.5): det 64, t = 288/64 = 4.5;
+    both (flat) boxes are entered at 4.5.  Hand-derived from BVHTraversal.cuh:51,63-70: d1 > d2 is false, so child 2 is pushed
+    first and child 1 is VISITED first; its triangle sets closest.t = 4.5; child 2 survives `closest.t < d` (4.5 < 4.5 is
+    false) and its triangle fails `t < closest.t`: the triangle of child 1 wins."""
+    pos = np.float32([[[-2, -2, .5], [2, -2, .5], [-2, 2, .5]], [[-4, -4, .5], [4, -4, .5], [-4, 4, .5]]])
+    nrm = np.tile(np.float32([0, 0, 1]), (2, 3, 1))
+    materials = [((1.0, 0.0, 0.0), -1), ((0.0, 1.0, 0.0), -1)]      # A red, B green
+    return pos, nrm, np.zeros((2, 3, 2), np.float32), np.int32([0, 1]), materials
+
+
+def tie_winner_albedo(nodes, tris_material, materials):
+    root = nodes[-1]
+    assert len(nodes) == 3 and not root["is_leaf"]
+    c1, c2 = nodes[int(root["child1"])], nodes[int(root["child2"])]
+    assert c1["is_leaf"] and c2["is_leaf"] and c1["prim_count"] == c2["prim_count"] == 1
+    return np.float32(materials[int(tris_material[int(c1["prim_start"])])][0])
+
+
+def test_equal_distances_and_equal_hits_resolve_as_in_the_reference():
+    """Oracle side of the hand-derived traversal KAT (see tie_scene): debug view ALBEDO shows the winner's colour."""
+    pos, nrm, uv, mat, materials = tie_scene()
+    tris = np.zeros(2, oracle.TRI_DTYPE)
+    a = [np.ascontiguousarray(x, np.float32) for x in (pos.reshape(-1, 3), nrm.reshape(-1, 3), uv.reshape(-1, 2))]
+    oracle.lib().o_build_triangles(a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, mat.ctypes.data, 2, tris.ctypes.data)
+    osc = oracle.Scene(tris, materials, []).build_bvh(1, 8)
+    want = tie_winner_albedo(osc.nodes, osc.tris["material"], materials)
+    cam = oracle.default_camera(position=(-0.5, -0.5, 5.0), forward=(0, 0, -1), vfov_rad=0.0)     # zero field of view: every pixel's ray is exactly (o, d)
+    img, _, _ = oracle.render(osc, cam, oracle.default_settings(render_mode=1, debug_mode=0, ray_bounce_limit=0, tone_mapping=0, gamma_correction=0), 4, 4, 1, 1)
+    assert np.array_equal(img[..., :3], np.broadcast_to(want, (4, 4, 3))), (img[0, 0], want)
+    # and the other way round when the near box differs: lift A's plane a little -> A is closer, A wins whatever the order
+    pos2 = pos.copy(); pos2[0, :, 2] = 0.75
+    oracle.lib().o_build_triangles(np.ascontiguousarray(pos2.reshape(-1, 3)).ctypes.data, a[1].ctypes.data, a[2].ctypes.data, mat.ctypes.data, 2, tris.ctypes.data)
+    osc2 = oracle.Scene(tris, materials, []).build_bvh(1, 8)
+    img2, _, _ = oracle.render(osc2, cam, oracle.default_settings(render_mode=1, debug_mode=0, ray_bounce_limit=0, tone_mapping=0, gamma_correction=0), 4, 4, 1, 1)
+    assert np.array_equal(img2[0, 0, :3], np.float32([1, 0, 0]))
