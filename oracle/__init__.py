@@ -145,9 +145,9 @@ class Scene:
             self._tex_c[i].data = padded.ctypes.data
 
     @classmethod
-    def load_glb(cls, path):
+    def load_glb(cls, path, strict=False):
         from .gltf_flatten import flatten
-        d = flatten(path)
+        d = flatten(path, strict=strict)
         n = len(d["mat"])
         tris = np.zeros(n, TRI_DTYPE)
         lib().o_build_triangles(_ptr(d["pos"]), _ptr(d["nrm"]), _ptr(d["uv"]),

@@ -29,6 +29,9 @@ SCENES = {
     "uv_texture_gltf": ("UVtextureTest.gltf", (0.0, 1.0, 4.0), (0.0, -0.1, -1.0), 3),
     "suzanne_plane_gltf": ("suzanne_plane.gltf", (0.0, 1.2, 4.5), (0.0, -0.15, -1.0), 2),
     "lightweight_rt": (os.path.join("test", "lightweightRTtest.glb"), (0.0, 1.8, 7.5), (0.0, -0.1, -1.0), 3),
+    # the reference's own scene-hierarchy test scene (models/sceneHierTest.glb): 12 nodes / meshes, index accessors shared by
+    # several meshes, three embedded images
+    "scene_hier_test": ("sceneHierTest.glb", (6.0, 3.0, 7.0), (-0.6, -0.2, -0.7), 3),
 }
 
 

@@ -298,11 +298,8 @@ def test_strict_loading_equals_reference_loading_where_the_assumptions_hold(name
     assert np.array_equal(a.m_Material["albedo_tex"], b.m_Material["albedo_tex"])
 
 
-def test_strict_loading_honours_what_the_reference_ignores(tmp_path):
-    """A GLB built to break every assumption of Scene.cu:120-200: u32 indices behind an accessor byteOffset, interleaved
-    vertices (byteStride), a parent node with translation + rotation + scale, a child with a matrix, an empty node, the
-    same mesh used by two nodes, a primitive without NORMAL / TEXCOORD_0 / material / indices, texture -> image
-    indirection.  Expected geometry is computed here with numpy in float64."""
+def _write_assumption_breaking_glb(tmp_path, want_locals=False):
+    """The GLB of test_strict_loading_honours_what_the_reference_ignores (see there)."""
     import json
     import struct
     rng = np.random.default_rng(11)
@@ -362,6 +359,16 @@ def test_strict_loading_honours_what_the_reference_ignores(tmp_path):
     glb = b"glTF" + struct.pack("<II", 2, 12 + 8 + len(js) + 8 + len(binary)) + struct.pack("<I", len(js)) + b"JSON" + js + struct.pack("<I", len(binary)) + b"BIN\0" + binary
     path = tmp_path / "strict.glb"
     path.write_bytes(glb)
+    return locals() if want_locals else path
+
+
+def test_strict_loading_honours_what_the_reference_ignores(tmp_path):
+    """A GLB built to break every assumption of Scene.cu:120-200: u32 indices behind an accessor byteOffset, interleaved
+    vertices (byteStride), a parent node with translation + rotation + scale, a child with a matrix, an empty node, the
+    same mesh used by two nodes, a primitive without NORMAL / TEXCOORD_0 / material / indices, texture -> image
+    indirection.  Expected geometry is computed here with numpy in float64."""
+    L = _write_assumption_breaking_glb(tmp_path, want_locals=True)
+    path, q, quad_p, quad_n, quad_t, tri_p, idx32, child_matrix = (L[k] for k in ("path", "q", "quad_p", "quad_n", "quad_t", "tri_p", "idx32", "child_matrix"))
 
     sc = drt.Scene()
     sc.loadGLTFmodel(str(path), strict=True)
@@ -451,3 +458,63 @@ def test_recursive_build_numbers_the_nodes_like_the_reference_recursion(name, le
     import sys
     sys.setrecursionlimit(10000)
     assert shape(na, len(na) - 1) == shape(nb, len(nb) - 1)
+
+
+def _assert_same_records(sc, osc, what):
+    tris = sc.m_PrimitivesBuffer
+    assert len(tris) == len(osc.tris) > 0, what
+    assert np.array_equal(bits(tris["vertex"]["position"]), bits(osc.tris["p"])), what + ": positions"
+    assert np.array_equal(bits(tris["vertex"]["normal"]), bits(osc.tris["n"])), what + ": normals"
+    assert np.array_equal(bits(tris["vertex"]["uv"]), bits(osc.tris["uv"])), what + ": uvs"
+    assert np.array_equal(bits(tris["centroid"]), bits(osc.tris["centroid"])), what + ": centroids"
+    assert np.array_equal(bits(tris["face_normal"]), bits(osc.tris["face_n"])), what + ": face normals"
+    assert np.array_equal(tris["material"], osc.tris["material"]), what + ": materials"
+    mats = sc.m_Material
+    assert len(mats) == osc.n_mats and np.array_equal(mats["albedo_tex"], osc.mats["albedo_tex"][: osc.n_mats]), what + ": texture indices"
+    assert np.array_equal(bits(mats["albedo"]), bits(osc.mats["albedo"][: osc.n_mats]))
+    assert [(int(m["primitives_offset"]), int(m["tris_count"])) for m in sc.m_Meshes] == list(osc.meshes), what + ": mesh ranges"
+
+
+@pytest.mark.parametrize("name", ["scene_hier_test", "suzanne_plane_gltf", "room", "lightweight_rt", "cornell_box", "uv_texture_gltf", "multi_material"])
+def test_strict_loading_matches_the_independent_strict_restatement(name):
+    """DRT_LOAD_STRICT (the opt-in departure from Scene.cu:120-200: scene graph, node transforms, accessor offsets / strides /
+    component types, optional indices / normals / uvs / materials, texture -> image) against oracle/gltf_flatten.py's
+    strict mode -- a separate numpy restatement of the glTF 2.0 rules: the 128-byte triangle records, materials and mesh
+    ranges must agree bit for bit.  suzanne_plane.gltf has node translations, lightweightRTtest.glb nested nodes, room.glb a
+    mesh without TEXCOORD_0, sceneHierTest.glb (the reference's own hierarchy test scene) shared index accessors."""
+    sc = drt.Scene()
+    sc.loadGLTFmodel(scene_path(name), strict=True)
+    osc = oracle.Scene.load_glb(scene_path(name), strict=True)
+    _assert_same_records(sc, osc, name)
+
+
+def test_strict_loading_of_a_file_that_breaks_every_assumption_matches_the_restatement(tmp_path):
+    """The synthetic GLB of test_strict_loading_honours_what_the_reference_ignores (u32 indices behind an accessor byteOffset,
+    interleaved vertices, TRS parent + matrix child, an empty node, an instanced mesh, a primitive with positions only,
+    texture -> image indirection) through both strict loaders."""
+    path = _write_assumption_breaking_glb(tmp_path)
+    sc = drt.Scene()
+    sc.loadGLTFmodel(str(path), strict=True)
+    osc = oracle.Scene.load_glb(str(path), strict=True)
+    _assert_same_records(sc, osc, "synthetic")
+
+
+@pytest.mark.parametrize("field,value", [("count", -3), ("byteOffset", -8), ("count", 2 ** 62), ("byteOffset", 2 ** 62), ("count", 2 ** 33)])
+def test_strict_loader_refuses_accessors_that_would_wrap_the_range_check(tmp_path, field, value):
+    """A crafted file: a negative or enormous accessor count / byteOffset must be an error, not a wrapped size_t that slips past the
+    bufferView range check and reads outside the buffer."""
+    import json
+    import struct
+    pos = np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0]]).tobytes()
+    acc = {"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}
+    acc[field] = value
+    gltf = {"asset": {"version": "2.0"}, "buffers": [{"byteLength": len(pos)}], "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": len(pos)}],
+            "accessors": [acc], "meshes": [{"primitives": [{"attributes": {"POSITION": 0}}]}], "nodes": [{"mesh": 0}], "scenes": [{"nodes": [0]}]}
+    js = json.dumps(gltf).encode()
+    js += b" " * ((-len(js)) % 4)
+    blob = struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js) + 8 + len(pos)) + struct.pack("<I4s", len(js), b"JSON") + js + struct.pack("<I4s", len(pos), b"BIN\0") + pos
+    path = tmp_path / "crafted.glb"
+    path.write_bytes(blob)
+    with pytest.raises(drt.DrtError) as e:
+        drt.Scene().loadGLTFmodel(str(path), strict=True)
+    assert e.value.code in (drt.ERR_PARSE, drt.ERR_INVALID, drt.ERR_UNSUPPORTED), e.value
