@@ -648,12 +648,14 @@ void path_pool_leaf_classes(const std::vector<LeafRange> &leaves, uint32_t out[3
 
 bool path_pool_supports(const SceneView &sc, const FrameParams &fp, int bvh_depth, bool scene_has_alpha, size_t scene_lds_bytes) {
     if (fp.render_mode != 0 || fp.enable_sunlight || scene_has_alpha) return false;       // lean paths only (so far)
-    if (scene_lds_bytes > kLdsSceneBytes || sc.n_tris >= 4095u || bvh_depth > 200) return false;
+    static const size_t scene_limit = std::getenv("DRT_POOL_SCENE_KB") ? (size_t)std::atoi(std::getenv("DRT_POOL_SCENE_KB")) * 1024 : kLdsSceneBytes;
+    if (scene_lds_bytes > scene_limit || sc.n_tris >= 4095u || bvh_depth > 200) return false;
     if (fp.bounce_limit > 60000) return false;                                            // the bounce index is kept in 16 bits
     if (sc.root_ref == kNoNode) return false;
     // a pool of at least 256 paths has to fit the CU's LDS next to the scene copy (a very deep tree's stacks may not leave room)
     const uint32_t stack_entries = (uint32_t)std::max(bvh_depth, 1);
-    if (pool_layout(256u, 256u, stack_entries, pool_scene_bytes(sc), 0u).total > 160u * 1024u) return false;
+    if (pool_layout(512u, 512u, stack_entries, pool_scene_bytes(sc), 0u).total > 160u * 1024u &&
+        (scene_lds_bytes > kLdsSceneBytes || pool_layout(256u, 256u, stack_entries, pool_scene_bytes(sc), 0u).total > 160u * 1024u)) return false;
     return true;
 }
 

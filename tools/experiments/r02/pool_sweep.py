@@ -1,7 +1,7 @@
 """GPU box: sweep path_pool launch parameters on one workload.  usage: pool_sweep.py scene W H frames depth  (env sets in the list below)"""
 import os, sys, itertools
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tools.pool_check import run
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+from tools.pool_check import run  # (tools/pool_check.py)
 
 if __name__ == "__main__":
     name, W, H, frames, depth = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])

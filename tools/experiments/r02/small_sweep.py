@@ -1,6 +1,6 @@
 """GPU box: Render() (one frame per call) at 1080p on cornell under several path_pool settings."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 import dustraytracer_amd as drt
 from tests.scenes import SCENES, scene_path
