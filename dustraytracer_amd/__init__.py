@@ -78,6 +78,14 @@ class RendererSettings(C.Structure):
             _assign(self, k, v)
 
 
+class MaterialModel(C.Structure):
+    """include/drt.h drt_material_model: opt-in emissive term / metallic lobe (NOT reference behaviour; all zero = reference image)."""
+    _fields_ = [("emissive", C.c_int32), ("specular", C.c_int32), ("emissive_scale", C.c_float), ("_reserved", C.c_int32)]
+
+    def __init__(self, emissive=0, specular=0, emissive_scale=1.0):
+        super().__init__(int(emissive), int(specular), float(emissive_scale), 0)
+
+
 class _CameraPOD(C.Structure):
     _fields_ = [("exposure", C.c_float), ("vfov_rad", C.c_float), ("defocus_angle", C.c_float),
                 ("focus_dist", C.c_float), ("position", C.c_float * 3), ("forward", C.c_float * 3)]
@@ -188,6 +196,9 @@ _sig("drt_scene_add_material", C.c_int, _P, C.POINTER(C.c_float), C.c_int32)
 _sig("drt_scene_add_texture", C.c_int, _P, _P, C.c_int32, C.c_int32, C.c_int32)
 _sig("drt_scene_build_bvh", C.c_int, _P, C.c_int32, C.c_int32)
 _sig("drt_scene_validate", C.c_int, _P)
+_sig("drt_scene_add_material_ex", C.c_int, _P, _P)
+_sig("drt_pcg_hash", C.c_uint32, C.c_uint32)
+_sig("drt_random_float", C.c_float, C.POINTER(C.c_uint32))
 _sig("drt_scene_build_bvh_recursive", C.c_int, _P, C.c_int32, C.c_int32)
 _sig("drt_scene_build_bvh_device", C.c_int, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float))
 for _n in ("triangle", "node", "material", "texture", "mesh"):
@@ -218,6 +229,8 @@ _sig("drt_renderer_bind_buffers", C.c_int, _P, _P, _P)
 _sig("drt_renderer_set_stream", C.c_int, _P, _P)
 _sig("drt_renderer_set_counting", C.c_int, _P, C.c_int32)
 _sig("drt_renderer_get_counters", C.c_int, _P, C.POINTER(Counters))
+_sig("drt_renderer_set_material_model", C.c_int, _P, _P)
+_sig("drt_renderer_get_material_model", C.c_int, _P, _P)
 _sig("drt_renderer_kernel_info", C.c_int, _P, C.c_char_p, C.c_size_t)
 _sig("drt_renderer_kernel_span", C.c_int, _P, C.POINTER(C.c_float))
 _sig("drt_renderer_launch_count", C.c_int32, _P)
@@ -307,6 +320,12 @@ class Scene:
     def addMaterial(self, albedo, albedo_tex=-1):
         a = (C.c_float * 3)(*albedo)
         return _check(_lib.drt_scene_add_material(self._h, a, albedo_tex))
+
+    def addMaterialEx(self, albedo, albedo_tex=-1, emissive=(0, 0, 0), roughness=0.0, metallic=False):
+        """A material with the fields only the opt-in material model reads (Renderer.setMaterialModel)."""
+        m = np.zeros(1, MATERIAL_DTYPE)
+        m["albedo"], m["emissive"], m["albedo_tex"], m["roughness"], m["metallic"], m["refractive_index"] = albedo, emissive, albedo_tex, roughness, int(bool(metallic)), 1.45
+        return _check(_lib.drt_scene_add_material_ex(self._h, m.ctypes.data))
 
     def addTexture(self, texels):
         t = np.ascontiguousarray(texels, np.uint8)
@@ -465,6 +484,11 @@ class Renderer:
 
     def _push_settings(self):
         _check(_lib.drt_renderer_set_settings(self._h, C.byref(self.m_RendererSettings)))
+
+    def setMaterialModel(self, emissive=0, specular=0, emissive_scale=1.0):
+        """Opt-in extension (drt_material_model): emissive term and / or metallic lobe.  Off (the default) = the reference's image."""
+        m = MaterialModel(emissive, specular, emissive_scale)
+        _check(_lib.drt_renderer_set_material_model(self._h, C.byref(m)))
 
     def Render(self, cam, scene):
         """One frame index; returns the kernel time in ms (the reference's `float* delta`)."""

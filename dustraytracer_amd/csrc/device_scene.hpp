@@ -40,6 +40,9 @@ static_assert(sizeof(TriCold) == 32, "TriCold layout");
 
 struct alignas(16) MatDev { float albedo[3]; int32_t tex; };
 struct alignas(16) TexDev { int32_t width, height, comps; uint32_t offset; };
+// Material fields the reference loads and never reads (Material.cuh:9,17,20; Scene.cu:71-75): only the opt-in material model
+// (drt_renderer_set_material_model) reads them, and only the general kernel
+struct alignas(16) MatExt { float emissive[3]; float roughness; int32_t metallic; int32_t _pad[3]; };
 
 // Host-side image of the device buffers.
 struct PackedScene {
@@ -48,6 +51,7 @@ struct PackedScene {
     std::vector<TriHot> tri_hot;
     std::vector<TriCold> tri_cold;
     std::vector<MatDev> mats;
+    std::vector<MatExt> mats_ext;
     std::vector<TexDev> texs;
     std::vector<uint8_t> texels;     // every texture followed by (width+1) zero texels (latent OOB read of Texture.cu:35-49)
     uint32_t root_ref = kNoNode;
@@ -64,6 +68,7 @@ struct SceneView {
     const TriHot *tri_hot;
     const TriCold *tri_cold;
     const MatDev *mats;
+    const MatExt *mats_ext;
     const TexDev *texs;
     const uint8_t *texels;
     uint32_t n_inner, n_leaves, n_tris, n_mats, n_texs;
@@ -104,6 +109,9 @@ struct FrameParams {
     int32_t vote_tail_node, vote_tail_shade;   // thresholds once the sample queue is empty (drain of the launch)
     int32_t leaf_chain;                        // T steps take the next leaf off the stack themselves (shallow trees)
     uint32_t row_step;                         // wave_queue work order: stride over the tile rows, coprime to their number
+    // opt-in material model (not reference behaviour; all zero = the reference's image): see include/drt.h drt_material_model
+    int32_t ext_emissive, ext_specular;
+    float ext_emissive_scale;
     int32_t inline_resolve;                    // the launch holds ONE frame: the tracing kernel adds each sample to the running sum and
                                                // writes the resolved texel itself (RenderKernel.cu:29-34), no sample buffer, no resolve kernel
 };

@@ -123,6 +123,8 @@ struct drt_renderer {
     DeviceArray<TriHot> d_hot;
     DeviceArray<TriCold> d_cold;
     DeviceArray<MatDev> d_mats;
+    DeviceArray<MatExt> d_mats_ext;
+    drt_material_model material_model = { 0, 0, 1.0f, 0 };
     DeviceArray<TexDev> d_texs;
     DeviceArray<uint8_t> d_texels;
     SceneView view;
@@ -132,7 +134,7 @@ struct drt_renderer {
     float *cur_rgba() const { return ext_rgba ? ext_rgba : rgba; }
     void free_scene() {
         d_inner.release(); d_leaves.release(); d_hot.release(); d_cold.release();
-        d_mats.release(); d_texs.release(); d_texels.release();
+        d_mats.release(); d_mats_ext.release(); d_texs.release(); d_texels.release();
         uploaded_scene = nullptr;
     }
 };
@@ -212,6 +214,27 @@ int drt_scene_add_material(drt_scene *s, const float albedo[3], int32_t albedo_t
         s->host.revision = HostScene::next_revision();
         return (int)s->host.materials.size() - 1;
     } catch (...) { return from_exception(); }
+}
+
+int drt_scene_add_material_ex(drt_scene *s, const drt_material *m) {
+    if (!s || !m) return fail(DRT_ERR_INVALID, "null argument");
+    try {
+        s->host.materials.push_back(*m);
+        s->host.revision = HostScene::next_revision();
+        return (int)s->host.materials.size() - 1;
+    } catch (...) { return from_exception(); }
+}
+
+// CudaMath/Random.cu:6-17 on the host (integer hash; the float conversion is exact arithmetic): what a host-side Sampler draws from
+uint32_t drt_pcg_hash(uint32_t input) {
+    uint32_t state = input * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+float drt_random_float(uint32_t *seed) {
+    if (!seed) return 0.f;
+    *seed = drt_pcg_hash(*seed);
+    return (float)*seed / 4294967296.0f;
 }
 
 int drt_scene_add_texture(drt_scene *s, const uint8_t *texels, int32_t width, int32_t height, int32_t components) {
@@ -436,6 +459,16 @@ int drt_renderer_set_settings(drt_renderer *r, const drt_settings *s) {
     r->settings = *s;
     return DRT_OK;
 }
+int drt_renderer_set_material_model(drt_renderer *r, const drt_material_model *m) {
+    if (!r || !m) return fail(DRT_ERR_INVALID, "null argument");
+    r->material_model = *m;
+    return DRT_OK;
+}
+int drt_renderer_get_material_model(const drt_renderer *r, drt_material_model *out) {
+    if (!r || !out) return fail(DRT_ERR_INVALID, "null argument");
+    *out = r->material_model;
+    return DRT_OK;
+}
 int drt_renderer_get_settings(const drt_renderer *r, drt_settings *out) {
     if (!r || !out) return fail(DRT_ERR_INVALID, "null argument");
     *out = r->settings;
@@ -530,11 +563,12 @@ static int upload_scene(drt_renderer *r, const drt_scene *scene) {
     HIP_TRY(r->d_hot.upload(ps.tri_hot));
     HIP_TRY(r->d_cold.upload(ps.tri_cold));
     HIP_TRY(r->d_mats.upload(ps.mats));
+    HIP_TRY(r->d_mats_ext.upload(ps.mats_ext));
     HIP_TRY(r->d_texs.upload(ps.texs));
     HIP_TRY(r->d_texels.upload(ps.texels));
     SceneView &v = r->view;
     v.inner = r->d_inner.ptr; v.leaves = r->d_leaves.ptr; v.tri_hot = r->d_hot.ptr; v.tri_cold = r->d_cold.ptr;
-    v.mats = r->d_mats.ptr; v.texs = r->d_texs.ptr; v.texels = r->d_texels.ptr;
+    v.mats = r->d_mats.ptr; v.mats_ext = r->d_mats_ext.ptr; v.texs = r->d_texs.ptr; v.texels = r->d_texels.ptr;
     v.n_inner = (uint32_t)ps.inner.size(); v.n_leaves = (uint32_t)ps.leaves.size();
     v.n_tris = (uint32_t)ps.tri_hot.size(); v.n_mats = (uint32_t)ps.mats.size(); v.n_texs = (uint32_t)ps.texs.size();
     v.root_ref = ps.root_ref;
@@ -582,6 +616,8 @@ static void fill_frame_params(const drt_renderer *r, const drt_camera *cam, Fram
     fp.enable_sunlight = s.enable_sunlight != 0;
     fp.bounce_limit = s.ray_bounce_limit;
     fp.render_mode = s.render_mode; fp.debug_mode = s.debug_mode;
+    fp.ext_emissive = r->material_model.emissive != 0; fp.ext_specular = r->material_model.specular != 0;
+    fp.ext_emissive_scale = r->material_model.emissive_scale;
     fp.width = r->width; fp.height = r->height;
     fp.stripe_rows = r->stripe_rows; fp.rank = r->rank; fp.world = r->world; fp.local_rows = r->local_rows;
     fp.accum = r->cur_accum(); fp.rgba = r->cur_rgba();
@@ -624,7 +660,8 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
     if (r->counting) HIP_TRY(hipMemsetAsync(r->counters, 0, sizeof(drt_counters), r->stream));
 
     HIP_TRY(hipEventRecord(r->ev_start, r->stream));                   // Renderer.cu:97
-    if (r->use_pixel_walk) {
+    const bool material_ext = fp.ext_emissive || fp.ext_specular;          // only the general wave_queue kernel implements it
+    if (r->use_pixel_walk && !material_ext) {
         HIP_TRY(launch_render(r->view, fp, r->bvh_depth, r->counting, r->stream, &r->kernel_name));
         r->launches_last = 1;
     } else {
@@ -650,12 +687,12 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
                 r->counters_used = 0;
             }
             unsigned int *const queue_head = r->tile_counter + r->counters_used++;
-            if (r->use_path_pool && !r->counting &&
+            if (r->use_path_pool && !r->counting && !material_ext &&
                 path_pool_supports(r->view, fp, r->bvh_depth, r->scene_has_alpha, wave_queue_scene_lds_bytes(r->view)))
                 HIP_TRY(launch_path_pool(r->view, fp, r->bvh_depth, r->pool_t_class, r->pool_tuning, r->pool_scratch, queue_head, r->samples, r->pool_status,
                                          r->num_cus, r->stream, &r->kernel_name, r->launch_shape));
             else
-            HIP_TRY(launch_wave_queue(r->view, fp, r->bvh_depth, r->counting ? 2 : 0, r->scene_has_alpha, queue_head,
+            HIP_TRY(launch_wave_queue(r->view, fp, r->bvh_depth, r->counting ? 2 : (material_ext ? 1 : 0), r->scene_has_alpha, queue_head,
                                       r->samples, r->num_cus, r->stream, &r->kernel_name, r->launch_shape, r->wq_cache));
         }
     }

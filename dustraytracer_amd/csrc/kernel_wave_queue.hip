@@ -298,6 +298,10 @@ __global__ __launch_bounds__(kBigThreads) DRT_OCCUPANCY_ATTR void wave_queue_ker
                     const bool front_face = closest_hit_frame(ray, hit_t, fetch_face_normal(hit_prim), position, normal);
                     const TriCold cold = fetch_cold(hit_prim);                             // :111-118
                     const MatDev mat = fetch_mat(cold.material);
+                    // opt-in material model (drt.h drt_material_model; not reference behaviour, general kernel only): emission seen
+                    // through the path so far, before this hit's albedo
+                    if (GENERAL && fp.ext_emissive && !debug)
+                        light = light + (ld3(sc.mats_ext[cold.material].emissive) * fp.ext_emissive_scale) * throughput;
                     if (mat.tex < 0) {
                         throughput = throughput * ld3(mat.albedo);
                         if (COUNT) c_hflat++;
@@ -309,6 +313,18 @@ __global__ __launch_bounds__(kBigThreads) DRT_OCCUPANCY_ATTR void wave_queue_ker
                     bounce_origin = position + (normal * 0.001f);                          // :121
                     if (SUN) { if (!front_face) hit_prim = ~hit_prim; }                    // normal = +-face normal of hit_prim: re-derived at launch
                     else bounce_normal = normal;
+                    if (GENERAL && fp.ext_specular && !debug) {
+                        // opt-in: a Metallic material reflects; the mirror direction takes the normal's place until the fuzz is drawn,
+                        // the roughness rides in tex_uv (only the UV debug view reads that) and the normal is re-derived from hit_prim
+                        const MatExt ext = sc.mats_ext[cold.material];
+                        tex_uv.x = 0;
+                        if (ext.metallic) {
+                            const f3 v = normalize(ray.dir);
+                            bounce_normal = v - normal * (2.0f * dot(v, normal));
+                            tex_uv.x = 1; tex_uv.y = ext.roughness;
+                            if (!front_face) hit_prim = ~hit_prim;
+                        }
+                    }
                     stage = kShadowDone;                                                   // (b) below, now or after the shadow ray
                     occluded = true;
                     if (sun) {                                                             // :124-128
@@ -352,14 +368,24 @@ __global__ __launch_bounds__(kBigThreads) DRT_OCCUPANCY_ATTR void wave_queue_ker
             // (b2) direction ready: launch the bounce ray  RayGen.cuh:133-134
             if (in_s && stage == kNeedDir && spec < 0) {
                 seed = spec_seed;
+                bool absorbed = false;
                 if (SUN) {
                     const f3 fn = fetch_face_normal(hit_prim < 0 ? ~hit_prim : hit_prim);
                     ray = make_ray(bounce_origin, (hit_prim < 0 ? (-1.f * fn) : fn) + spec_p);
+                } else if (GENERAL && fp.ext_specular && !debug && tex_uv.x != 0) {
+                    const f3 fn = fetch_face_normal(hit_prim < 0 ? ~hit_prim : hit_prim);
+                    const f3 n = hit_prim < 0 ? (-1.f * fn) : fn;
+                    const f3 dir = bounce_normal + spec_p * tex_uv.y;                      // reflect(...) + roughness * fuzz
+                    absorbed = !(dot(dir, n) > 0.0f);                                      // scattered into the surface: the path ends
+                    ray = make_ray(bounce_origin, dir);
                 } else
                 ray = make_ray(bounce_origin, bounce_normal + spec_p);
-                begin_closest();
-                stage = kTraceDone;
-                arm_direction();
+                if (absorbed) { stage = kPathDone; sp = 0; cur = end = 0; spec = 0; }
+                else {
+                    begin_closest();
+                    stage = kTraceDone;
+                    arm_direction();
+                }
             }
             // (c) path finished: post-process and park the sample's colour  RayGen.cuh:165-171
             if (in_s && stage == kPathDone) {

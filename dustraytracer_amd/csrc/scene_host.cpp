@@ -807,6 +807,12 @@ PackedScene HostScene::pack() const {
         std::memcpy(d.albedo, m.albedo, 12);
         d.tex = m.albedo_tex;
         ps.mats.push_back(d);
+        MatExt e;
+        std::memset(&e, 0, sizeof e);
+        std::memcpy(e.emissive, m.emissive, 12);
+        e.roughness = m.roughness;
+        e.metallic = m.metallic ? 1 : 0;
+        ps.mats_ext.push_back(e);
     }
     for (const HostTexture &t : textures) {
         TexDev d;

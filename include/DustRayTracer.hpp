@@ -195,6 +195,35 @@ public:
     }
 };
 
+// Core/Sampler.cuh:5-13: the interface the reference declares and never implements (PCGSampler is an empty class there, RayGen.cuh
+// seeds by hand).  Here PCGSampler is the RayGen recipe behind that interface, on the host: seed = (x + y * width) * sampleidx
+// (RayGen.cuh:74-75), + dimension (the bounce index, :91), draws = randomFloat (Random.cu:13-17) -- the numbers a path of the
+// kernels draws, for tools that want to follow one.
+class Sampler {
+public:
+    virtual ~Sampler() = default;
+    virtual void StartSampler(float2_ pixel, uint32_t sampleidx, int dimension) = 0;   // dim replaces bounces
+    virtual float Get1DSample() = 0;
+    virtual float2_ Get2DSample() = 0;
+    virtual float2_ GetPixel2D() = 0;
+};
+class PCGSampler : public Sampler {
+public:
+    explicit PCGSampler(uint32_t image_width) : m_width(image_width) {}
+    void StartSampler(float2_ pixel, uint32_t sampleidx, int dimension) override {
+        m_pixel = pixel;
+        m_seed = ((uint32_t)pixel.x + (uint32_t)pixel.y * m_width) * sampleidx + (uint32_t)dimension;
+    }
+    float Get1DSample() override { return drt_random_float(&m_seed); }
+    float2_ Get2DSample() override { float2_ v; v.x = drt_random_float(&m_seed); v.y = drt_random_float(&m_seed); return v; }
+    float2_ GetPixel2D() override { return m_pixel; }
+    uint32_t seed() const { return m_seed; }
+    void setSeed(uint32_t s) { m_seed = s; }
+private:
+    uint32_t m_width, m_seed = 0;
+    float2_ m_pixel = { 0, 0 };
+};
+
 // Core/Renderer.hpp:14-47.  Renderer(device) renders on one GPU; Renderer({0, 1, ..., 7}) renders on several GPUs of the
 // node (drt_group_*: framebuffer stripes per device, gathered into the first device's image over RCCL) behind the same calls.
 class Renderer {
@@ -231,6 +260,12 @@ public:
     uint32_t getSampleCount() const { return drt_renderer_sample_count(handle); }
     void resetAccumulationBuffer() { drt::check(group ? drt_group_reset(group) : drt_renderer_reset(handle)); }
     int deviceCount() const { return group ? (int)drt_group_size(group) : 1; }
+    // opt-in material model (drt.h drt_material_model; off = the reference's image): emissive term, metallic lobe
+    void setMaterialModel(bool emissive, bool specular, float emissive_scale = 1.0f) {
+        drt_material_model m = { emissive ? 1 : 0, specular ? 1 : 0, emissive_scale, 0 };
+        const int n = deviceCount();
+        for (int i = 0; i < n; i++) drt::check(drt_renderer_set_material_model(group ? drt_group_renderer(group, i) : handle, &m));
+    }
 
     // replaces GLuint& GetRenderTargetImage_name(): RGBA32F, row 0 = bottom, width*height*4 floats
     void ReadRenderTarget(float *dst) {

@@ -55,6 +55,19 @@ typedef struct drt_settings {
     float   sky_intensity;         /* :34 */
 } drt_settings;
 
+/* Opt-in material model -- NOT reference behaviour.  The reference loads emissiveFactor, roughnessFactor and
+ * metallicFactor (Scene.cu:71-75, Material.cuh:9,17,20) and its kernel reads none of them (RayGen.cuh:111-134).  With everything
+ * zero (the default) the image is the reference's, bit for bit.  emissive != 0: a hit adds  EmmisiveFactor * emissive_scale *
+ * throughput  (the throughput before that hit's albedo).  specular != 0: a hit on a Metallic material continues along
+ * reflect(normalize(ray.dir), N) + Roughness * randomUnitSphereVec3(seed)  -- the same random draws as the diffuse bounce -- and the
+ * path ends if that direction points into the surface.  Rendered by the general wave_queue kernel. */
+typedef struct drt_material_model {
+    int32_t emissive;
+    int32_t specular;
+    float   emissive_scale;        /* default 1 */
+    int32_t _reserved;
+} drt_material_model;
+
 /* Core/Scene/Camera.cuh:30-47: the fields the kernel reads (Camera.cu:82-123). */
 typedef struct drt_camera {
     float exposure;                /* :32 */
@@ -139,6 +152,10 @@ int        drt_scene_load_gltf_ex(drt_scene *s, const char *path, uint32_t flags
 int        drt_scene_set_geometry(drt_scene *s, const float *positions, const float *normals, const float *uvs,
                                   const int32_t *material_ids, int32_t n_tris);
 int        drt_scene_add_material(drt_scene *s, const float albedo[3], int32_t albedo_tex);
+int        drt_scene_add_material_ex(drt_scene *s, const drt_material *m);   /* every field (emissive, roughness, metallic: drt_material_model) */
+/* CudaMath/Random.cu:6-17 on the host: the RNG the kernels use (pcg_hash; randomFloat = hash, then seed / 2^32 in [0, 1]). */
+uint32_t   drt_pcg_hash(uint32_t input);
+float      drt_random_float(uint32_t *seed);
 int        drt_scene_add_texture(drt_scene *s, const uint8_t *texels, int32_t width, int32_t height, int32_t components);
 int        drt_scene_build_bvh(drt_scene *s, int32_t target_leaf_prims, int32_t bin_count);  /* BVHBuilder::buildIterative */
 /* The same build run on GPU `device`: identical nodes, node order and triangle order -- a bound that
@@ -168,6 +185,8 @@ drt_renderer *drt_renderer_create(int32_t device);                            /*
 void          drt_renderer_destroy(drt_renderer *r);                          /* Renderer::~Renderer */
 int           drt_renderer_resize(drt_renderer *r, uint32_t width, uint32_t height);   /* ResizeBuffer: no-op for equal size, else realloc + reset */
 int           drt_renderer_set_settings(drt_renderer *r, const drt_settings *s);       /* writes m_RendererSettings (caller resets, EditorLayer.cpp:241-277) */
+int           drt_renderer_set_material_model(drt_renderer *r, const drt_material_model *m);   /* see drt_material_model */
+int           drt_renderer_get_material_model(const drt_renderer *r, drt_material_model *out);
 int           drt_renderer_get_settings(const drt_renderer *r, drt_settings *out);
 /* Render: ONE frame index, blocking, returns kernel ms in *delta_ms (Renderer.cu:80-117). No-op when sample_count == max_samples. */
 int           drt_renderer_render(drt_renderer *r, const drt_camera *cam, const drt_scene *scene, float *delta_ms);

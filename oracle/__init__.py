@@ -18,6 +18,7 @@ NODE_DTYPE = np.dtype([("is_leaf", "<i4"), ("bmin", "<f4", 3), ("bmax", "<f4", 3
 TRI_DTYPE = np.dtype([("centroid", "<f4", 3), ("p", "<f4", (3, 3)), ("n", "<f4", (3, 3)),
                       ("uv", "<f4", (3, 2)), ("face_n", "<f4", 3), ("material", "<i4")])
 MAT_DTYPE = np.dtype([("albedo", "<f4", 3), ("albedo_tex", "<i4")])
+MAT_EXT_DTYPE = np.dtype([("emissive", "<f4", 3), ("roughness", "<f4"), ("metallic", "<i4")])
 assert NODE_DTYPE.itemsize == 44 and TRI_DTYPE.itemsize == 124 and MAT_DTYPE.itemsize == 16
 
 
@@ -40,7 +41,8 @@ class Camera(C.Structure):
 
 class SceneC(C.Structure):
     _fields_ = [("tris", C.c_void_p), ("n_tris", C.c_int32), ("nodes", C.c_void_p), ("n_nodes", C.c_int32),
-                ("mats", C.c_void_p), ("n_mats", C.c_int32), ("texs", C.c_void_p), ("n_texs", C.c_int32)]
+                ("mats", C.c_void_p), ("n_mats", C.c_int32), ("texs", C.c_void_p), ("n_texs", C.c_int32),
+                ("mats_ext", C.c_void_p), ("ext_emissive", C.c_int32), ("ext_specular", C.c_int32), ("ext_emissive_scale", C.c_float)]
 
 
 class Counters(C.Structure):
@@ -125,7 +127,11 @@ def _ptr(a):
 class Scene:
     """Triangles + BVH + materials + textures held as numpy arrays for the C oracle."""
 
-    def __init__(self, tris, materials, textures):
+    def __init__(self, tris, materials, textures, materials_ext=None):
+        self.mats_ext = np.zeros(max(len(materials), 1), MAT_EXT_DTYPE)          # (emissive3, roughness, metallic) per material
+        for i, e in enumerate(materials_ext or []):
+            self.mats_ext[i]["emissive"], self.mats_ext[i]["roughness"], self.mats_ext[i]["metallic"] = e
+        self.material_model = (0, 0, 1.0)                                        # opt-in extension: (emissive, specular, emissive_scale)
         self.tris = np.ascontiguousarray(tris, dtype=TRI_DTYPE)
         self.nodes = np.zeros(0, NODE_DTYPE)
         self.mats = np.zeros(max(len(materials), 1), MAT_DTYPE)
@@ -152,7 +158,7 @@ class Scene:
         tris = np.zeros(n, TRI_DTYPE)
         lib().o_build_triangles(_ptr(d["pos"]), _ptr(d["nrm"]), _ptr(d["uv"]),
                                 _ptr(np.ascontiguousarray(d["mat"], np.int32)), n, _ptr(tris))
-        sc = cls(tris, d["materials"], d["textures"])
+        sc = cls(tris, d["materials"], d["textures"], d.get("materials_ext"))
         sc.meshes = d["meshes"]
         return sc
 
@@ -174,6 +180,8 @@ class Scene:
         s.nodes, s.n_nodes = self.nodes.ctypes.data, len(self.nodes)
         s.mats, s.n_mats = self.mats.ctypes.data, self.n_mats
         s.texs, s.n_texs = C.addressof(self._tex_c), len(self.textures)
+        s.mats_ext = self.mats_ext.ctypes.data
+        s.ext_emissive, s.ext_specular, s.ext_emissive_scale = int(self.material_model[0]), int(self.material_model[1]), float(self.material_model[2])
         return s
 
 

@@ -503,6 +503,9 @@ static f3 ray_gen(uint32_t x, uint32_t y, uint32_t max_x, uint32_t max_y, const 
         }
 
         const o_material *mat = &sc->mats[payload.prim->material];                          /* :111-118 */
+        const o_material_ext *ext = sc->mats_ext ? &sc->mats_ext[payload.prim->material] : NULL;
+        if (ext && sc->ext_emissive && !debug)                       /* opt-in (o_scene): emission seen through the path so far */
+            light = add3(light, mul3(scale3(ld3(ext->emissive), sc->ext_emissive_scale), throughput));
         if (mat->albedo_tex < 0) {
             throughput = mul3(throughput, ld3(mat->albedo));
             if (cnt) cnt->hits_flat++;
@@ -521,8 +524,15 @@ static f3 ray_gen(uint32_t x, uint32_t y, uint32_t max_x, uint32_t max_y, const 
                 light = add3(light, mul3(sf->suncol, throughput));
         }
 
-        ray = make_ray(new_origin, add3(payload.normal,                                     /* :133-134 */
-                                        random_unit_sphere_vec3(&seed, cnt ? &cnt->sphere_iters : NULL)));
+        f3 fuzz = random_unit_sphere_vec3(&seed, cnt ? &cnt->sphere_iters : NULL);
+        if (ext && sc->ext_specular && ext->metallic && !debug) {   /* opt-in: mirror lobe, fuzzed by the roughness */
+            f3 v = normalize3(ray.dir);
+            f3 refl = sub3(v, scale3(payload.normal, 2.0f * dot3(v, payload.normal)));
+            f3 dir = add3(refl, scale3(fuzz, ext->roughness));
+            if (!(dot3(dir, payload.normal) > 0.0f)) break;          /* scattered into the surface: absorbed */
+            ray = make_ray(new_origin, dir);
+        } else
+        ray = make_ray(new_origin, add3(payload.normal, fuzz));                             /* :133-134 */
 
         if (debug) {                                                                        /* :137-161 */
             switch (set->debug_mode) {

@@ -86,11 +86,26 @@ typedef struct {
     float forward[3];
 } o_camera;
 
+/* Core/Scene/Material.cuh:9,17,20 -- fields the reference loads (Scene.cu:71-75) and never reads; used only by the opt-in
+ * material model below. */
+typedef struct {
+    float   emissive[3];    /* EmmisiveFactor */
+    float   roughness;      /* Roughness */
+    int32_t metallic;       /* Metallic (metallicFactor > 0) */
+} o_material_ext;
+
+/* Opt-in extension (NOT reference behaviour; everything 0 / NULL = the reference's image, bit for bit):
+ *   emissive  a hit adds  EmmisiveFactor * emissive_scale * throughput  (the throughput before this hit's albedo)
+ *   specular  a hit on a Metallic material continues along  reflect(normalize(ray.dir), N) + Roughness * randomUnitSphereVec3
+ *             (the same draws as the diffuse bounce; the path ends if that points into the surface) instead of N + ... */
 typedef struct {
     const o_triangle *tris;   int32_t n_tris;
     const o_bvh_node *nodes;  int32_t n_nodes;   /* root = n_nodes-1 (Kernel/TraceRay.cu:20) */
     const o_material *mats;   int32_t n_mats;
     const o_texture  *texs;   int32_t n_texs;
+    const o_material_ext *mats_ext;              /* n_mats entries, or NULL */
+    int32_t ext_emissive, ext_specular;
+    float   ext_emissive_scale;
 } o_scene;
 
 /* Exact work counters; summed over everything rendered. */

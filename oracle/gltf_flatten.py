@@ -131,12 +131,15 @@ def flatten(path, strict=False):
             data = from_uri(img["uri"], [os.path.join("..", "models"), base_dir])
         textures.append(_decode_image(data))
 
-    materials = []
+    materials, materials_ext = [], []
     for m in gltf.get("materials", []):
         pbr = m.get("pbrMetallicRoughness", {})
         col = pbr.get("baseColorFactor", [1.0, 1.0, 1.0, 1.0])
         tex = pbr.get("baseColorTexture", {}).get("index", -1)
         materials.append((np.array(col[:3], dtype=np.float64).astype(np.float32), int(tex)))
+        # Scene.cu:71-75: loaded by the reference, read by nothing; tinygltf defaults 1 / 1 / (0, 0, 0)
+        materials_ext.append((np.array(m.get("emissiveFactor", [0.0, 0.0, 0.0]), np.float64).astype(np.float32),
+                              np.float32(pbr.get("roughnessFactor", 1.0)), int(pbr.get("metallicFactor", 1.0) > 0)))
 
     if strict:
         jtex = gltf.get("textures", [])
@@ -144,7 +147,8 @@ def flatten(path, strict=False):
         geo = flatten_strict(gltf, buffers, n_file_materials=len(materials))
         if geo.pop("default_material_used"):
             materials.append((np.float32([1, 1, 1]), -1))                                           # the specification's default material
-        return dict(materials=materials, textures=textures, **geo)
+            materials_ext.append((np.float32([0, 0, 0]), np.float32(1.0), 1))
+        return dict(materials=materials, materials_ext=materials_ext, textures=textures, **geo)
 
     pos_all, nrm_all, uv_all, mat_all, meshes = [], [], [], [], []
     n_prims = 0
@@ -186,7 +190,7 @@ def flatten(path, strict=False):
     mat = np.concatenate(mat_all) if mat_all else np.zeros((0,), np.int32)
     if len(pos) % 3 or len(mat) != len(pos) // 3:
         raise ValueError("index/material bookkeeping mismatch (Scene.cu:166-175 would misindex)")
-    return dict(pos=pos, nrm=nrm, uv=uv, mat=mat, materials=materials, textures=textures, meshes=meshes)
+    return dict(pos=pos, nrm=nrm, uv=uv, mat=mat, materials=materials, materials_ext=materials_ext, textures=textures, meshes=meshes)
 
 
 # ------------------------------------------------------------------------------------------------------------------------

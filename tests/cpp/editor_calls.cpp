@@ -56,6 +56,17 @@ int main(int argc, char **argv) {
         std::printf("settings: %d %d %d %d %d %.3f %.1f %.3f %.3f %.3f %.1f | %.4f %.1f %.1f %.1f\n", *b0, *b1, *b2, *i0, *i1, f0[1], *f1, *f2, *f3, f4[2], *f5,
                     *c0, *c1, *c2, *c3);
 
+        // Core/Sampler.cuh:5-13 through its interface: the draws of pixel (57, 0), sample index 5 of a 1920-wide frame = seed 285,
+        // then the known-answer sequence of randomFloat from seed 12345 (tests/golden/kat_ref.npz, the reference's own Random.cu)
+        PCGSampler pcg(1920);
+        Sampler *sampler = &pcg;
+        sampler->StartSampler(float2_{ 57.f, 0.f }, 5, 0);
+        std::printf("sampler: seed=%u pixel=%.0f,%.0f\n", pcg.seed(), sampler->GetPixel2D().x, sampler->GetPixel2D().y);
+        pcg.setSeed(12345);
+        const float d0 = sampler->Get1DSample();
+        const float2_ d12 = sampler->Get2DSample();
+        std::printf("sampler: draws=%a,%a,%a\n", d0, d12.x, d12.y);
+
         if (render) {                              // OnUIRender / OnUpdate, EditorLayer.cpp:137,212,317-318,424
             Renderer m_Renderer;
             float m_LastRenderTime_ms = 0;

@@ -31,6 +31,9 @@ SCENES = {
     "lightweight_rt": (os.path.join("test", "lightweightRTtest.glb"), (0.0, 1.8, 7.5), (0.0, -0.1, -1.0), 3),
     # the reference's own scene-hierarchy test scene (models/sceneHierTest.glb): 12 nodes / meshes, index accessors shared by
     # several meshes, three embedded images
+    # the reference's test scene for the material features it loads and never reads: three emissive cubes (blue, red,
+    # green), a metallic sphere of roughness 0, a teapot on a textured floor
+    "emissive_test": (os.path.join("test", "EmissiveTest.glb"), (0.0, 0.9, 2.2), (0.0, -0.3, -1.0), 4),
     "scene_hier_test": ("sceneHierTest.glb", (6.0, 3.0, 7.0), (-0.6, -0.2, -0.7), 3),
 }
 

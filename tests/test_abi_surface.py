@@ -199,6 +199,9 @@ def test_editor_statements_compile_against_the_wrapper(tmp_path):
     out = subprocess.run([str(exe), os.path.join(ROOT, "models", "cs16_dust.glb")], capture_output=True, text=True, check=True).stdout
     assert "objects=1 triangles=11167 materials=23 textures=23 root=1" in out     # the editor's metrics panel
     assert "settings: 0 1 1 2 500 0.944 30.0 -0.803 0.681 0.800 20.0 | 1.0472 10.0 0.0 1.0" in out
+    # Core/Sampler.cuh's interface, implemented (PCGSampler): RayGen's seed recipe, and the reference's own randomFloat sequence
+    assert "sampler: seed=285 pixel=57,0" in out
+    assert "sampler: draws=0x1.e8bd5ap-1,0x1.55b33p-2,0x1.4d657ep-4" in out              # kat_ref.npz randfloat(12345)[:3]
 
 
 @pytest.mark.gpu
