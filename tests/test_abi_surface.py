@@ -209,3 +209,53 @@ def test_editor_statements_render(tmp_path):
     exe = _build_editor_calls(tmp_path)
     out = subprocess.run([str(exe), os.path.join(ROOT, "models", "cornell_box.glb"), "--render"], capture_output=True, text=True, check=True).stdout
     assert "rendered 160 x 90, sample 2" in out
+
+
+def _build_gl_shim(tmp_path):
+    exe = tmp_path / "editor_gl_shim"
+    lib_dir = os.path.dirname(drt.LIB_PATH)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "editor_gl_shim.cpp"),
+                    "-L" + lib_dir, "-ldrt_hip", "-ldl", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    return exe
+
+
+def test_editor_gl_shim_displays_and_saves_like_the_editor(tmp_path):
+    """include/DustRayTracerGL.hpp: the GL half of the render target the reference fills through CUDA-GL interop (Renderer.cu:42-94),
+    the viewport texture (EditorLayer.cpp:293-295) and "save png" (EditorLayer.cpp:23-31, 85-96: glGetTexImage as RGBA8, rows
+    flipped).  Compiled warning-free and run with a software texture in place of OpenGL: the PNG must hold the frame clamped to
+    [0, 1], scaled to 8 bits and upside down."""
+    import numpy as np
+    from PIL import Image
+    exe = _build_gl_shim(tmp_path)
+    base = tmp_path / "image"
+    out = subprocess.run([str(exe), str(base)], capture_output=True, text=True, check=True).stdout
+    assert "shown texture 1, 37 x 21, uploads 2" in out and "Image saved" in out
+    png = np.asarray(Image.open(str(base) + ".png"))
+    assert png.shape == (21, 37, 4)
+    W, H = 37, 21
+    x = (np.arange(W, dtype=np.float32) / np.float32(W - 1) * np.float32(1.5) - np.float32(0.25))
+    y = np.arange(H, dtype=np.float32) / np.float32(H - 1)
+    want = np.zeros((H, W, 4), np.float32)
+    want[..., 0], want[..., 1], want[..., 2], want[..., 3] = x[None, :], y[:, None], 0.5, 1.0
+    want8 = np.rint(np.clip(want, 0, 1) * np.float32(255)).astype(np.uint8)[::-1]          # flipped: the frame's row 0 is the bottom
+    assert np.array_equal(png, want8)
+
+
+@pytest.mark.gpu
+def test_editor_gl_shim_shows_a_rendered_frame(tmp_path):
+    import numpy as np
+    from PIL import Image
+    exe = _build_gl_shim(tmp_path)
+    base = tmp_path / "frame"
+    out = subprocess.run([str(exe), str(base), os.path.join(ROOT, "models", "cornell_box.glb")], capture_output=True, text=True, check=True).stdout
+    assert "160 x 90, sample 4, uploads 3" in out and "Image saved" in out
+    png = np.asarray(Image.open(str(base) + ".png"))
+    r = drt.Renderer(0)
+    sc = drt.Scene(); sc.loadGLTFmodel(os.path.join(ROOT, "models", "cornell_box.glb"))
+    b = drt.BVHBuilder(); b.m_TargetLeafPrimitivesCount, b.m_BinCount = 20, 8; b.buildIterative(sc)
+    cam = drt.Camera((3.6, 1.25, 0.0)); cam.m_Forward_dir = np.float32([-1, 0, 0])
+    r.ResizeBuffer(160, 90)
+    for _ in range(3):
+        r.Render(cam, sc)
+    want8 = np.rint(np.clip(r.GetRenderTargetImage(), 0, 1) * np.float32(255)).astype(np.uint8)[::-1]
+    assert np.array_equal(png, want8)
