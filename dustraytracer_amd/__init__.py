@@ -580,6 +580,7 @@ class Renderer:
             b, l, t = int(a[3 * k]), int(a[3 * k + 1]), int(a[3 * k + 2])
             out[name] = (b, l / max(b, 1), t)
         out["claim_ticks"], out["idle_polls"], out["lost_claims"], out["wave_ticks"] = int(a[24]), int(a[25]), int(a[26]), int(a[27])
+        out["failed_claims"], out["failed_claim_ticks"], out["idle_ticks"] = int(a[28]), int(a[29]), int(a[30])
         return out
 
     def launchesOfLastBatch(self):

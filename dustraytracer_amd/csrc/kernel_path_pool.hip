@@ -168,7 +168,16 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     {
         const uint4 *g_inner = reinterpret_cast<const uint4 *>(sc.inner);
         const uint4 *g_hot = reinterpret_cast<const uint4 *>(sc.tri_hot);
-        for (uint32_t i = tid; i < sc.n_inner * 4u; i += wg) st4(lds_inner + i * 16u, g_inner[i]);
+        // (leaf references are rewritten while the records are staged: kLeafBit | count << 12 | first triangle -- reaching a leaf
+        // then costs no LeafRange load; n_tris < 4096 is what path_pool_supports guarantees)
+        for (uint32_t i = tid; i < sc.n_inner * 4u; i += wg) {
+            uint4 v = g_inner[i];
+            if ((i & 3u) == 3u) {
+                if (v.x & kLeafBit) { const LeafRange lr = sc.leaves[v.x & ~kLeafBit]; v.x = kLeafBit | ((uint32_t)lr.count << 12) | (uint32_t)lr.start; }
+                if (v.y & kLeafBit) { const LeafRange lr = sc.leaves[v.y & ~kLeafBit]; v.y = kLeafBit | ((uint32_t)lr.count << 12) | (uint32_t)lr.start; }
+            }
+            st4(lds_inner + i * 16u, v);
+        }
         for (uint32_t i = tid; i < sc.n_tris * 3u; i += wg) st4(lds_hot + i * 16u, g_hot[i]);
         for (uint32_t i = tid; i < sc.n_leaves; i += wg) st2(lds_leaf + i * 8u, make_uint2((uint32_t)sc.leaves[i].start, (uint32_t)sc.leaves[i].count));
         if (cold_lds) {
@@ -230,21 +239,22 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         return t;
     };
     // leaf -> (first triangle, end) packed with the stack height, and the T queue of its size class
-    auto leaf_state = [&](uint32_t leaf_id, int sp, uint32_t &packed) -> int {
-        const uint2 lr = ld2(lds_leaf + leaf_id * 8u);
-        const uint32_t cur = lr.x, end = lr.x + lr.y;
-        packed = cur | (end << 12) | ((uint32_t)sp << 24);
-        const uint32_t steps = (lr.y + 1u) >> 1;
+    auto leaf_state = [&](uint32_t leaf_ref, int sp, uint32_t &packed) -> int {          // leaf_ref = count << 12 | first triangle
+        const uint32_t cur = leaf_ref & 0xFFFu, count = leaf_ref >> 12;
+        packed = cur | ((cur + count) << 12) | ((uint32_t)sp << 24);
+        const uint32_t steps = (count + 1u) >> 1;
         return QT0 + (steps <= pp.t_class[0] ? 0 : (steps <= pp.t_class[1] ? 1 : (steps <= pp.t_class[2] ? 2 : 3)));
     };
     // traversal over: a path with a hit is shaded (B), one without ends on the sky (E)
     auto after_traversal = [&](float hit_t) -> int { return hit_t < FLT_MAX ? QB : QE; };
-    // One pop of BVHTraversal.cuh:33-72 for a path whose stack holds sp > 0 entries.  Returns the T queue when the path now
-    // stands on a leaf (packed = its triangle range + stack height), else -1 (popped entry culled, or an interior node whose
-    // children went on the stack).  (ray.dir is not used: the slab test needs the origin and 1/dir.)
-    auto pop_step = [&](const Ray &ray, float hit_t, int &sp, uint32_t id, uint32_t &packed) -> int {
-        --sp;
-        const uint2 e = ld2(stack + ((uint32_t)sp * P + id) * 8u);
+    // One visit of BVHTraversal.cuh:33-72.  The entry to visit is `top` when have_top is set (an entry that would have been pushed
+    // and popped again at once: it never goes through LDS), else the stack's top.  Returns the T queue when the path now stands on
+    // a leaf (packed = its triangle range + stack height), else -1 (entry culled, or an interior node: its far child went on
+    // the stack, its near child -- the next visit -- into `top`).  (ray.dir is not used: the slab test needs origin and 1/dir.)
+    auto pop_step = [&](const Ray &ray, float hit_t, int &sp, uint32_t id, uint32_t &packed, uint2 &top, bool &have_top) -> int {
+        uint2 e = top;
+        if (!have_top) { --sp; e = ld2(stack + ((uint32_t)sp * P + id) * 8u); }
+        have_top = false;
         int dest = -1;
         // :41 (without a hit, hit_t = FLT_MAX > dist); :38 was applied when the root was pushed
         if (!(hit_t < u2f(e.y))) {
@@ -258,13 +268,18 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 const float da = first_is_1 ? d1 : d2, db = first_is_1 ? d2 : d1;
                 if (da < hit_t) { st2(stack + ((uint32_t)sp * P + id) * 8u, make_uint2(ra, f2u(da))); ++sp; }
                 if (db < hit_t) {
-                    // a near child that is a leaf is this path's next visit and passes :41 (nothing changes hit_t in between)
+                    // the near child is this path's next visit and passes :41 (nothing changes hit_t in between): a leaf goes
+                    // straight to T, an interior node stays in registers
                     if (rb & kLeafBit) dest = leaf_state(rb & ~kLeafBit, sp, packed);
-                    else { st2(stack + ((uint32_t)sp * P + id) * 8u, make_uint2(rb, f2u(db))); ++sp; }
+                    else { top = make_uint2(rb, f2u(db)); have_top = true; }
                 }
             }
         }
         return dest;
+    };
+    // a path leaves a batch with an entry still in registers: it goes on the stack after all
+    auto spill_top = [&](int &sp, uint32_t id, const uint2 &top, bool &have_top) {
+        if (have_top) { st2(stack + ((uint32_t)sp * P + id) * 8u, top); ++sp; have_top = false; }
     };
     // Push every lane's path id (dest >= 0) to its destination queue: one atomic add per destination present in the wave
     // (issued together by the first lane of each group), then the ids go to consecutive ring positions.
@@ -295,21 +310,30 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     };
     const f3 root_min = ld3(sc.root_min), root_max = ld3(sc.root_max);
     // TraceRay.cu:15-20 + BVHTraversal.cuh:22-26,38: the root goes on the stack with its slab distance when -1 < d < FLT_MAX
-    auto begin_closest = [&](const Ray &ray, uint32_t id) -> int {
-        if (sc.root_ref == kNoNode) return 0;
+    uint32_t root_ref = sc.root_ref;                      // (a one-leaf scene: the same self-describing form as the staged records)
+    if (root_ref != kNoNode && (root_ref & kLeafBit)) { const LeafRange lr = sc.leaves[root_ref & ~kLeafBit]; root_ref = kLeafBit | ((uint32_t)lr.count << 12) | (uint32_t)lr.start; }
+    auto begin_closest = [&](const Ray &ray, uint2 &top) -> bool {
+        if (sc.root_ref == kNoNode) return false;
         const float d = slab_intersect(root_min, root_max, ray);
-        if (!(-1.0f < d && d < FLT_MAX)) return 0;
-        st2(stack + id * 8u, make_uint2(sc.root_ref, f2u(d)));
-        return 1;
+        if (!(-1.0f < d && d < FLT_MAX)) return false;
+        top = make_uint2(root_ref, f2u(d));
+        return true;
     };
     // A new ray: root on the stack, first pop done right away (every lane of the batch needs it), state stored.
     // Returns the queue the path goes to.
     auto launch_ray = [&](uint32_t id, const Ray &ray, uint32_t bounce, bool trace) -> int {
-        int sp = trace ? begin_closest(ray, id) : 0;
+        int sp = 0;
+        uint2 top = make_uint2(0u, 0u);
+        bool have_top = trace && begin_closest(ray, top);
         uint32_t packed = 0;
         int dest = -1;
-        if (sp > 0) dest = pop_step(ray, FLT_MAX, sp, id, packed);
-        if (dest < 0) { packed = (uint32_t)sp << 24; dest = sp > 0 ? QN : QE; }       // QE: the ray missed the scene's bounds -> sky
+        if (have_top) dest = pop_step(ray, FLT_MAX, sp, id, packed, top, have_top);     // the root's visit
+        if (dest < 0) {
+            spill_top(sp, id, top, have_top);
+            packed = (uint32_t)sp << 24;
+            dest = sp > 0 ? QN : QE;                                                     // QE: nothing to traverse -> sky
+        }
+
         st4(qA + id * 16u, make_uint4(f2u(ray.orig.x), f2u(ray.orig.y), f2u(ray.orig.z), f2u(FLT_MAX)));
         st4(qB + id * 16u, make_uint4(f2u(ray.dir.x), f2u(ray.dir.y), f2u(ray.dir.z), packed));
         st1(qW + id * 4u, kNoPrim | (bounce << 12) | kHasSample);
@@ -318,7 +342,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
 
     const int wave = tid >> 6;
     uint32_t polls = 0, idle_polls = 0, rot = (uint32_t)wave;
-    unsigned long long s_batches[kNQ], s_lanes[kNQ], s_ticks[kNQ], s_claim = 0, s_idle = 0, s_lost = 0;
+    unsigned long long s_batches[kNQ], s_lanes[kNQ], s_ticks[kNQ], s_claim = 0, s_idle = 0, s_lost = 0, s_fail = 0, s_fail_ticks = 0, s_idle_ticks = 0;
     for (int k = 0; k < kNQ; k++) s_batches[k] = s_lanes[k] = s_ticks[k] = 0;
     const unsigned long long s_t_start = STATS ? __builtin_amdgcn_s_memtime() : 0;
     unsigned long long s_t0 = s_t_start;
@@ -352,34 +376,40 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         if (q < 0) {
             if (live == 0) break;                                         // every pool slot retired: the launch is done
             __builtin_amdgcn_s_sleep(8);
-            if (STATS) s_idle++;
+            if (STATS) { s_idle++; s_idle_ticks += __builtin_amdgcn_s_memtime() - s_t0; }
             if (++idle_polls > (1u << 22)) { st1_shared(ctrl + kCtrlAbort, 1u); if (lane == 0 && pp.status) atomicOr(pp.status, 1u); break; }
             continue;
         }
         if ((uint32_t)avail < pp.min_fill && polls < pp.patience && exhausted == 0) {
             ++polls;
-            if (STATS) s_idle++;
             __builtin_amdgcn_s_sleep(2);
+            if (STATS) { s_idle++; s_idle_ticks += __builtin_amdgcn_s_memtime() - s_t0; }
             continue;
         }
         uint32_t head = (uint32_t)__builtin_amdgcn_readlane((int)my_ctrl.x, q);
         const uint32_t tail = (uint32_t)__builtin_amdgcn_readlane((int)my_ctrl.y, q);
         uint32_t n = (uint32_t)min(avail, 64);
         int won = 0;
-        // compare-and-swap on the head; a wave that loses the race knows the new head and tries again for what is left
-        for (int attempt = 0; attempt < 4 && !won; attempt++) {
+        // compare-and-swap on the head; a wave that loses the race reads the queue's head and tail again (one LDS load, every lane
+        // the same address) and tries for what is there now -- cheaper than choosing a queue afresh
+        uint32_t tail_now = tail;
+        for (int attempt = 0; attempt < 6 && !won; attempt++) {
             uint32_t seen = head;
             if (lane == 0) won = lds_cas_seen(ctrl + (uint32_t)q * 8u, head, head + n, seen) ? 1 : 0;
             won = __builtin_amdgcn_readfirstlane(won);
             if (won) break;
             if (STATS) s_lost++;
-            head = (uint32_t)__builtin_amdgcn_readfirstlane((int)seen);
-            const int left = (int)(tail - head);
-            if (left < (int)pp.min_fill) break;
+            const uint2 ht = ld2_shared(ctrl + (uint32_t)q * 8u);
+            head = (uint32_t)__builtin_amdgcn_readfirstlane((int)ht.x);
+            tail_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)ht.y);
+            const int left = (int)(tail_now - head);
+            if (left < (int)pp.min_fill && exhausted == 0) break;
+            if (left <= 0) break;
             n = (uint32_t)min(left, 64);
         }
+        (void)tail_now;
         ++rot;
-        if (!won) continue;                                               // the queue went to other waves: look again
+        if (!won) { if (STATS) { s_fail++; s_fail_ticks += __builtin_amdgcn_s_memtime() - s_t0; } continue; }   // the queue went to other waves: look again
         polls = 0; idle_polls = 0;
         const bool active = (uint32_t)lane < n;
         uint32_t id = 0;
@@ -440,15 +470,17 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 hit_t = u2f(A.w);
                 ray = make_ray(mk3(u2f(A.x), u2f(A.y), u2f(A.z)), mk3(u2f(B.x), u2f(B.y), u2f(B.z)));     // 1/dir again (Ray.cuh:7-9): 12 bytes of LDS per path saved
             }
+            uint2 top = make_uint2(0u, 0u);
+            bool have_top = false;
             for (uint32_t it = 0;; ++it) {
-                const bool go = active && dest < 0 && sp > 0;
+                const bool go = active && dest < 0 && (have_top || sp > 0);
                 const unsigned long long m_go = pp_ballot(go);
                 // lanes that are done wait for the others only while enough of them are still popping
                 if (m_go == 0 || it >= pp.n_loop || (it > 0 && (uint32_t)__popcll(m_go) < pp.n_min_lanes)) break;
-                if (go) dest = pop_step(ray, hit_t, sp, id, packed);
+                if (go) dest = pop_step(ray, hit_t, sp, id, packed, top, have_top);
             }
             if (active) {
-                if (dest < 0) { packed = (uint32_t)sp << 24; dest = sp > 0 ? QN : after_traversal(hit_t); }
+                if (dest < 0) { spill_top(sp, id, top, have_top); packed = (uint32_t)sp << 24; dest = sp > 0 ? QN : after_traversal(hit_t); }
                 st1(qB + id * 16u + 12u, packed);
             }
         } else if (q >= QT0 && q < QB) {
@@ -612,6 +644,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         for (int k = 0; k < kNQ; k++) { atomicAdd(&pp.stats[3 * k], s_batches[k]); atomicAdd(&pp.stats[3 * k + 1], s_lanes[k]); atomicAdd(&pp.stats[3 * k + 2], s_ticks[k]); }
         atomicAdd(&pp.stats[3 * kNQ], s_claim); atomicAdd(&pp.stats[3 * kNQ + 1], s_idle); atomicAdd(&pp.stats[3 * kNQ + 2], s_lost);
         atomicAdd(&pp.stats[3 * kNQ + 3], __builtin_amdgcn_s_memtime() - s_t_start);
+        atomicAdd(&pp.stats[3 * kNQ + 4], s_fail); atomicAdd(&pp.stats[3 * kNQ + 5], s_fail_ticks); atomicAdd(&pp.stats[3 * kNQ + 6], s_idle_ticks);
     }
 }
 
