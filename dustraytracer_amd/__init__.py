@@ -573,14 +573,14 @@ class Renderer:
 
     def poolStats(self, reset=True):
         """path_pool statistics (renderer created with DRT_POOL_STATS=1): dict queue -> (batches, mean paths per batch, ticks)."""
-        a = np.zeros(32, np.uint64)
+        a = np.zeros(40, np.uint64)
         _check(_lib.drt_debug_pool_stats(self._h, a.ctypes.data, 1 if reset else 0))
         out = {}
-        for k, name in enumerate(("N", "T0", "T1", "T2", "T3", "B", "E", "R")):
+        for k, name in enumerate(("N", "T0", "T1", "T2", "T3", "B", "E", "R", "S")):
             b, l, t = int(a[3 * k]), int(a[3 * k + 1]), int(a[3 * k + 2])
             out[name] = (b, l / max(b, 1), t)
-        out["claim_ticks"], out["idle_polls"], out["lost_claims"], out["wave_ticks"] = int(a[24]), int(a[25]), int(a[26]), int(a[27])
-        out["failed_claims"], out["failed_claim_ticks"], out["idle_ticks"] = int(a[28]), int(a[29]), int(a[30])
+        out["claim_ticks"], out["idle_polls"], out["lost_claims"], out["wave_ticks"] = int(a[27]), int(a[28]), int(a[29]), int(a[30])
+        out["failed_claims"], out["failed_claim_ticks"], out["idle_ticks"] = int(a[31]), int(a[32]), int(a[33])
         return out
 
     def launchesOfLastBatch(self):

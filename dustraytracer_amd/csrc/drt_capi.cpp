@@ -364,8 +364,8 @@ drt_renderer *drt_renderer_create(int32_t device) {
     r->pool_tuning.cold_lds_kb = env_int("DRT_POOL_COLD_KB", r->pool_tuning.cold_lds_kb);
     r->pool_tuning.share_grid = env_int("DRT_POOL_SHARE_GRID", r->pool_tuning.share_grid);
     r->pool_tuning.dir_tries = env_int("DRT_POOL_DIR_TRIES", r->pool_tuning.dir_tries);
-    if (env_int("DRT_POOL_STATS", 0) != 0 && hipMalloc((void **)&r->pool_tuning.stats, 32 * sizeof(unsigned long long)) == hipSuccess)
-        (void)hipMemset(r->pool_tuning.stats, 0, 32 * sizeof(unsigned long long));
+    if (env_int("DRT_POOL_STATS", 0) != 0 && hipMalloc((void **)&r->pool_tuning.stats, 40 * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemset(r->pool_tuning.stats, 0, 40 * sizeof(unsigned long long));
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) r->num_cus = cus;
     int khz = 0;
@@ -397,6 +397,7 @@ void drt_renderer_destroy(drt_renderer *r) {
     if (r->pool_tuning.stats) (void)hipFree(r->pool_tuning.stats);
     if (r->pool_scratch.aux) (void)hipFree(r->pool_scratch.aux);
     if (r->pool_scratch.aux_slot) (void)hipFree(r->pool_scratch.aux_slot);
+    if (r->pool_scratch.aux_light) (void)hipFree(r->pool_scratch.aux_light);
     if (r->samples) (void)hipFree(r->samples);
     if (r->ev_start) (void)hipEventDestroy(r->ev_start);
     if (r->ev_stop) (void)hipEventDestroy(r->ev_stop);
@@ -689,7 +690,7 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
             unsigned int *const queue_head = r->tile_counter + r->counters_used++;
             if (r->use_path_pool && !r->counting && !material_ext &&
                 path_pool_supports(r->view, fp, r->bvh_depth, r->scene_has_alpha, wave_queue_scene_lds_bytes(r->view)))
-                HIP_TRY(launch_path_pool(r->view, fp, r->bvh_depth, r->pool_t_class, r->pool_tuning, r->pool_scratch, queue_head, r->samples, r->pool_status,
+                HIP_TRY(launch_path_pool(r->view, fp, r->bvh_depth, r->scene_has_alpha, r->pool_t_class, r->pool_tuning, r->pool_scratch, queue_head, r->samples, r->pool_status,
                                          r->num_cus, r->stream, &r->kernel_name, r->launch_shape));
             else
             HIP_TRY(launch_wave_queue(r->view, fp, r->bvh_depth, r->counting ? 2 : (material_ext ? 1 : 0), r->scene_has_alpha, queue_head,
@@ -851,13 +852,13 @@ int drt_debug_wave_queue_plans(const drt_renderer *r, char *buf, size_t cap) {
     return DRT_OK;
 }
 
-int drt_debug_pool_stats(drt_renderer *r, uint64_t out[32], int32_t reset) {
+int drt_debug_pool_stats(drt_renderer *r, uint64_t out[40], int32_t reset) {
     if (!r || !out) return fail(DRT_ERR_INVALID, "null argument");
     if (!r->pool_tuning.stats) return fail(DRT_ERR_INVALID, "renderer was not created with DRT_POOL_STATS=1");
     HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipStreamSynchronize(r->stream));
-    HIP_TRY(hipMemcpy(out, r->pool_tuning.stats, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(r->pool_tuning.stats, 0, 32 * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpy(out, r->pool_tuning.stats, 40 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(r->pool_tuning.stats, 0, 40 * sizeof(uint64_t)));
     return DRT_OK;
 }
 

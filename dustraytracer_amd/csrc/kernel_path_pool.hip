@@ -40,11 +40,14 @@ namespace drt {
 
 namespace {
 
-constexpr int kNQ = 8;                               // queues: N, T0..T3, B, E, R
-enum : int { QN = 0, QT0 = 1, QB = 5, QE = 6, QR = 7 };
+constexpr int kNQ = 9;                               // queues: N, T0..T3, B, E, R, S
+enum : int { QN = 0, QT0 = 1, QB = 5, QE = 6, QR = 7, QS = 8 };
 constexpr uint32_t kEmptyId = 0xFFFFu;
 constexpr uint32_t kNoPrim = 0xFFFu;                 // word W: hit triangle (12 bits, kNoPrim = none) | bounce index << 12 (16 bits) | kHasSample
 constexpr uint32_t kHasSample = 1u << 28;
+constexpr uint32_t kShadow = 1u << 29;               // the traversal under way is the sun's shadow ray (RayTest, BVHTraversal.cuh:76-134)
+constexpr uint32_t kBackFace = 1u << 30;             // the shaded hit was seen from behind: its normal is -face normal (ClosestHit.cuh:17-24)
+constexpr uint32_t kOccluded = 1u << 31;             // the shadow ray hit something
 constexpr int kMaxPoolThreads = 1024;                // up to 16 waves per workgroup = 4 per SIMD (128 VGPRs each)
 
 typedef uint32_t pp_u32x4 __attribute__((ext_vector_type(4)));
@@ -107,11 +110,12 @@ DRT_DEV uint32_t f2u(float f) { return __float_as_uint(f); }
 struct PoolLayout {
     uint32_t ctrl, rings, quads, words, stack, scene, cold, total;      // byte offsets; total = bytes needed
 };
-__host__ __device__ inline PoolLayout pool_layout(uint32_t P, uint32_t ring_cap, uint32_t stack_entries, uint32_t scene_bytes, uint32_t cold_bytes) {
+__host__ __device__ inline PoolLayout pool_layout(uint32_t P, uint32_t ring_cap, uint32_t stack_entries, uint32_t scene_bytes, uint32_t cold_bytes,
+                                                  uint32_t n_rings = (uint32_t)kNQ - 1u /* S's ring exists in sunlight builds only */) {
     PoolLayout l;
     l.ctrl = 0;                                     // head/tail pairs of the kNQ queues (8 B each), then {live, abort}, {exhausted, -}
     l.rings = 128;
-    l.quads = l.rings + (uint32_t)kNQ * ring_cap * 2u;
+    l.quads = l.rings + n_rings * ring_cap * 2u;
     l.words = l.quads + 2u * P * 16u;
     l.stack = l.words + P * 4u;
     l.scene = (l.stack + stack_entries * P * 8u + 15u) & ~15u;
@@ -119,7 +123,7 @@ __host__ __device__ inline PoolLayout pool_layout(uint32_t P, uint32_t ring_cap,
     l.total = l.cold + cold_bytes;
     return l;
 }
-constexpr uint32_t kCtrlLive = 64, kCtrlAbort = 68, kCtrlExhausted = 72;
+constexpr uint32_t kCtrlLive = 80, kCtrlAbort = 84, kCtrlExhausted = 88;      // (the pairs of lanes 10 and 11 of the control read)
 __host__ __device__ inline uint32_t pool_scene_bytes(const SceneView &sc) { return sc.n_inner * 64u + sc.n_tris * 48u + ((sc.n_leaves * 8u + 15u) & ~15u); }
 __host__ __device__ inline uint32_t pool_cold_bytes(const SceneView &sc) { return sc.n_tris * 32u + sc.n_mats * 16u + sc.n_texs * 16u; }
 
@@ -138,14 +142,17 @@ struct PoolParams {
     uint32_t cold_in_lds;      // TriCold / MatDev / TexDev records staged in LDS too (small scenes): B's loads chain through LDS
     uint32_t dir_tries;        // B and R draw at most this many candidates of the bounce direction per batch; paths still without one go (back) to R
     uint4 *aux;                // HBM, [workgroup][path]: {throughput, seed} -- what only B and E touch stays out of LDS
+    float4 *aux_light;         // HBM, [workgroup][path]: light gathered so far (sunlight builds; lean paths gather light only where they end)
     uint32_t *aux_slot;        // HBM, [workgroup][path]: where the path's sample goes in `samples`
     unsigned int *status;      // device word: != 0 after an aborted launch
     unsigned long long *stats; // STATS build: per queue {batches, lanes, ticks} (3 x kNQ), then claim ticks, idle polls, lost claims, wave ticks
 };
 
-template <bool STATS>
+// FLAGS: 1 = statistics, 2 = sunlight (a shadow ray per shaded hit, RayGen.cuh:124-128), 4 = alpha cut-outs (AnyHit.cuh:8-28)
+template <int FLAGS>
 __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneView sc, const FrameParams fp, const PoolParams pp,
                                                                     unsigned int *sample_counter, float4 *samples) {
+    constexpr bool STATS = (FLAGS & 1) != 0, SUN = (FLAGS & 2) != 0, ALPHA = (FLAGS & 4) != 0;
     extern __shared__ uint4 lds_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -153,7 +160,8 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     const uint32_t P = pp.P;
     const uint32_t ring_mask = pp.ring_cap - 1u;
     const bool cold_lds = pp.cold_in_lds != 0;
-    const PoolLayout lay = pool_layout(P, pp.ring_cap, pp.stack_entries, pool_scene_bytes(sc), cold_lds ? pool_cold_bytes(sc) : 0u);
+    constexpr uint32_t kRings = SUN ? (uint32_t)kNQ : (uint32_t)kNQ - 1u;
+    const PoolLayout lay = pool_layout(P, pp.ring_cap, pp.stack_entries, pool_scene_bytes(sc), cold_lds ? pool_cold_bytes(sc) : 0u, kRings);
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds_raw);      // low 32 bits of the flat address = LDS offset
     const uint32_t ctrl = lds_base + lay.ctrl, rings = lds_base + lay.rings, stack = lds_base + lay.stack;
     const uint32_t qA = lds_base + lay.quads, qB = qA + P * 16u, qW = lds_base + lay.words;
@@ -161,6 +169,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     const uint32_t lds_cold = lds_base + lay.cold, lds_mats = lds_cold + sc.n_tris * 32u, lds_texs = lds_mats + sc.n_mats * 16u;
     uint4 *const aux = pp.aux + (size_t)blockIdx.x * P;
     uint32_t *const aux_slot = pp.aux_slot + (size_t)blockIdx.x * P;
+    float4 *const aux_light = pp.aux_light + (size_t)blockIdx.x * P;
 
     if (fp.span && lane == 0) atomicMax(&fp.span[0], ~(unsigned long long)wall_clock64());
 
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             for (uint32_t i = tid; i < sc.n_mats; i += wg) st4(lds_mats + i * 16u, g_mats[i]);
             for (uint32_t i = tid; i < sc.n_texs; i += wg) st4(lds_texs + i * 16u, g_texs[i]);
         }
-        for (uint32_t i = tid; i < (uint32_t)kNQ * pp.ring_cap; i += wg) st_id(rings + i * 2u, kEmptyId);
+        for (uint32_t i = tid; i < kRings * pp.ring_cap; i += wg) st_id(rings + i * 2u, kEmptyId);
         for (uint32_t i = tid; i < 32u; i += wg) st1(ctrl + i * 4u, 0u);
         for (uint32_t i = tid; i < P; i += wg) st1(qW + i * 4u, kNoPrim);               // no sample yet
         __syncthreads();
@@ -246,7 +255,8 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         return QT0 + (steps <= pp.t_class[0] ? 0 : (steps <= pp.t_class[1] ? 1 : (steps <= pp.t_class[2] ? 2 : 3)));
     };
     // traversal over: a path with a hit is shaded (B), one without ends on the sky (E)
-    auto after_traversal = [&](float hit_t) -> int { return hit_t < FLT_MAX ? QB : QE; };
+    // (a shadow traversal: on to S, the second half of the shading)
+    auto after_traversal = [&](float hit_t, bool shadow) -> int { return shadow ? QS : (hit_t < FLT_MAX ? QB : QE); };
     // One visit of BVHTraversal.cuh:33-72.  The entry to visit is `top` when have_top is set (an entry that would have been pushed
     // and popped again at once: it never goes through LDS), else the stack's top.  Returns the T queue when the path now stands on
     // a leaf (packed = its triangle range + stack height), else -1 (entry culled, or an interior node: its far child went on
@@ -319,25 +329,33 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         top = make_uint2(root_ref, f2u(d));
         return true;
     };
-    // A new ray: root on the stack, first pop done right away (every lane of the batch needs it), state stored.
-    // Returns the queue the path goes to.
-    auto launch_ray = [&](uint32_t id, const Ray &ray, uint32_t bounce, bool trace) -> int {
+    // A new ray: the root's entry (`top`, when have_top) is visited right away (every lane of the batch needs that), the state is
+    // stored.  Returns the queue the path goes to.
+    auto launch_with = [&](uint32_t id, const Ray &ray, uint32_t w_word, uint2 top, bool have_top, bool shadow) -> int {
         int sp = 0;
-        uint2 top = make_uint2(0u, 0u);
-        bool have_top = trace && begin_closest(ray, top);
         uint32_t packed = 0;
         int dest = -1;
         if (have_top) dest = pop_step(ray, FLT_MAX, sp, id, packed, top, have_top);     // the root's visit
         if (dest < 0) {
             spill_top(sp, id, top, have_top);
             packed = (uint32_t)sp << 24;
-            dest = sp > 0 ? QN : QE;                                                     // QE: nothing to traverse -> sky
+            dest = sp > 0 ? QN : after_traversal(FLT_MAX, shadow);                       // nothing to traverse: sky (E) / not occluded (S)
         }
-
+        // hit distance FLT_MAX: for a shadow ray it stays there, so that N's culls (:41, :63-70) never apply -- RayTest has none
         st4(qA + id * 16u, make_uint4(f2u(ray.orig.x), f2u(ray.orig.y), f2u(ray.orig.z), f2u(FLT_MAX)));
         st4(qB + id * 16u, make_uint4(f2u(ray.dir.x), f2u(ray.dir.y), f2u(ray.dir.z), packed));
-        st1(qW + id * 4u, kNoPrim | (bounce << 12) | kHasSample);
+        st1(qW + id * 4u, w_word);
         return dest;
+    };
+    auto launch_ray = [&](uint32_t id, const Ray &ray, uint32_t bounce, bool trace) -> int {
+        uint2 top = make_uint2(0u, 0u);
+        const bool have_top = trace && begin_closest(ray, top);
+        return launch_with(id, ray, kNoPrim | (bounce << 12) | kHasSample, top, have_top, false);
+    };
+    // RayTest (BVHTraversal.cuh:76-134): the root is visited unless its slab test says "behind" (:95-103), no distance culls
+    auto launch_shadow = [&](uint32_t id, const Ray &ray, uint32_t w_word) -> int {
+        const bool have_top = sc.root_ref != kNoNode && !(slab_intersect(root_min, root_max, ray) < 0);
+        return launch_with(id, ray, w_word, make_uint2(root_ref, f2u(0.0f)), have_top, true);
     };
 
     const int wave = tid >> 6;
@@ -351,12 +369,12 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         // ---------------- choose a queue and claim up to 64 of its ids ----------------
         // Queues holding a full batch are shared out round robin (the waves of a workgroup would otherwise all race for
         // the same one); with none, the fullest queue is taken -- after a short wait for company unless the launch is draining.
-        // One LDS read fetches every control word: lanes 0..7 their queue's {head, tail}, lane 8 {live, abort}, lane 9 {exhausted}.
+        // One LDS read fetches every control word: lanes 0..8 their queue's {head, tail}, lane 10 {live, abort}, lane 11 {exhausted}.
         uint2 my_ctrl = make_uint2(0u, 0u);
-        if (lane < 10) my_ctrl = ld2_shared(ctrl + (uint32_t)lane * 8u);
+        if (lane < 12) my_ctrl = ld2_shared(ctrl + (uint32_t)lane * 8u);
         const int my_avail = lane < kNQ ? (int)(my_ctrl.y - my_ctrl.x) : 0;
-        const uint32_t live = (uint32_t)__builtin_amdgcn_readlane((int)my_ctrl.x, 8), aborted = (uint32_t)__builtin_amdgcn_readlane((int)my_ctrl.y, 8);
-        const uint32_t exhausted = (uint32_t)__builtin_amdgcn_readlane((int)my_ctrl.x, 9);
+        const uint32_t live = (uint32_t)__builtin_amdgcn_readlane((int)my_ctrl.x, 10), aborted = (uint32_t)__builtin_amdgcn_readlane((int)my_ctrl.y, 10);
+        const uint32_t exhausted = (uint32_t)__builtin_amdgcn_readlane((int)my_ctrl.x, 11);
         int q = -1, avail = 0;
         const unsigned full_mask = (unsigned)pp_ballot(my_avail >= 64) & ((1u << kNQ) - 1u);
         if (full_mask) {
@@ -464,11 +482,13 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             float hit_t = FLT_MAX;
             int sp = 0;
             uint32_t packed = 0;
+            bool shadow = false;
             if (active) {
                 const uint4 A = ld4(qA + id * 16u), B = ld4(qB + id * 16u);
                 sp = (int)(B.w >> 24);
                 hit_t = u2f(A.w);
                 ray = make_ray(mk3(u2f(A.x), u2f(A.y), u2f(A.z)), mk3(u2f(B.x), u2f(B.y), u2f(B.z)));     // 1/dir again (Ray.cuh:7-9): 12 bytes of LDS per path saved
+                if (SUN) shadow = (ld1(qW + id * 4u) & kShadow) != 0;
             }
             uint2 top = make_uint2(0u, 0u);
             bool have_top = false;
@@ -480,7 +500,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 if (go) dest = pop_step(ray, hit_t, sp, id, packed, top, have_top);
             }
             if (active) {
-                if (dest < 0) { spill_top(sp, id, top, have_top); packed = (uint32_t)sp << 24; dest = sp > 0 ? QN : after_traversal(hit_t); }
+                if (dest < 0) { spill_top(sp, id, top, have_top); packed = (uint32_t)sp << 24; dest = sp > 0 ? QN : after_traversal(hit_t, shadow); }
                 st1(qB + id * 16u + 12u, packed);
             }
         } else if (q >= QT0 && q < QB) {
@@ -489,11 +509,13 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             float hit_t = FLT_MAX;
             uint32_t hit_prim = kNoPrim;
             int cur = 0, end = 0, sp = 0;
+            bool shadow = false, occluded = false;
             if (active) {
                 const uint4 A = ld4(qA + id * 16u), B = ld4(qB + id * 16u);
                 ray.orig = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); hit_t = u2f(A.w);
                 ray.dir = mk3(u2f(B.x), u2f(B.y), u2f(B.z));
                 cur = (int)(B.w & 0xFFFu); end = (int)((B.w >> 12) & 0xFFFu); sp = (int)(B.w >> 24);
+                if (SUN) shadow = (ld1(qW + id * 4u) & kShadow) != 0;
             }
             const float hit_t_in = hit_t;
             while (pp_ballot(cur < end) != 0) {
@@ -506,12 +528,19 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                     float t0, u0, v0, t1, u1, v1;
                     const bool h0 = tri_intersect_flat(ray, ta.v0, ta.e1, ta.e2, t0, u0, v0);
                     const bool h1 = tri_intersect_flat(ray, tb.v0, tb.e1, tb.e2, t1, u1, v1) & two;
-                    // (the barycentrics are not kept: B computes them again for the one triangle that wins)
-                    if (h0 && t0 < hit_t) { hit_t = t0; hit_prim = (uint32_t)i; }
-                    if (h1 && t1 < hit_t) { hit_t = t1; hit_prim = (uint32_t)j; }
+                    if (SUN && shadow) {                                  // RayTest: any accepted hit ends the traversal (:105-117)
+                        const bool occ = (h0 && (!ALPHA || any_hit(sc, i, mk3(1.0f - u0 - v0, u0, v0)))) ||
+                                         (h1 && (!ALPHA || any_hit(sc, j, mk3(1.0f - u1 - v1, u1, v1))));
+                        if (occ) { occluded = true; cur = end; sp = 0; }
+                    } else {
+                        // (the barycentrics are not kept: B computes them again for the one triangle that wins)
+                        if (h0 && t0 < hit_t && (!ALPHA || any_hit(sc, i, mk3(1.0f - u0 - v0, u0, v0)))) { hit_t = t0; hit_prim = (uint32_t)i; }
+                        if (h1 && t1 < hit_t && (!ALPHA || any_hit(sc, j, mk3(1.0f - u1 - v1, u1, v1)))) { hit_t = t1; hit_prim = (uint32_t)j; }
+                    }
                 }
             }
             if (active) {
+                if (SUN && occluded) st1(qW + id * 4u, ld1(qW + id * 4u) | kOccluded);
                 if (hit_t < hit_t_in) {
                     st1(qA + id * 16u + 12u, f2u(hit_t));
                     st1(qW + id * 4u, (ld1(qW + id * 4u) & ~0xFFFu) | hit_prim);
@@ -525,7 +554,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                     if (e.x & kLeafBit) { --sp; dest = leaf_state(e.x & ~kLeafBit, sp, packed); }
                     break;
                 }
-                if (dest < 0) { packed = (uint32_t)sp << 24; dest = sp > 0 ? QN : after_traversal(hit_t); }
+                if (dest < 0) { packed = (uint32_t)sp << 24; dest = sp > 0 ? QN : after_traversal(hit_t, shadow); }
                 st1(qB + id * 16u + 12u, packed);
             }
         } else if (q == QR) {
@@ -556,22 +585,53 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 f3 throughput = mk3(u2f(E.x), u2f(E.y), u2f(E.z));
                 const f3 uvw = mk3(1.0f - hit_u - hit_v, hit_u, hit_v);                    // Intersection.cu:31
                 f3 position, normal;                                                       // ClosestHit.cuh:13-24
-                closest_hit_frame(ray, hit_t, fetch_face_normal(hit_prim), position, normal);
+                const bool front_face = closest_hit_frame(ray, hit_t, fetch_face_normal(hit_prim), position, normal);
                 const TriCold cold = fetch_cold(hit_prim);                                 // :111-118
                 const MatDev mat = fetch_mat(cold.material);
                 if (mat.tex < 0) throughput = throughput * ld3(mat.albedo);
                 else throughput = throughput * tex_get_pixel(sc, fetch_tex(mat.tex), interp_uv(cold, uvw));
                 const f3 origin = position + (normal * 0.001f);                            // :121
-                ++bounce;
-                if ((int)bounce <= fp.bounce_limit) {                                      // :88 loop condition
-                    need_dir = true; dir_origin = origin; dir_normal = normal; dir_seed = seed; dir_bounce = bounce; dir_tries = 0;
-                    dir_thr = throughput;
+                if (SUN) {
+                    // :124-128: the sun's shadow ray starts where the bounce ray will (its origin waits in A), the normal is found
+                    // again from the triangle and the side bit; the rest of this iteration is S's, after the shadow traversal
+                    const Ray sun_ray = make_ray(origin, ld3(fp.sunpos) + random_unit_vec3(seed) * 1.5f);
+                    aux[id] = make_uint4(f2u(throughput.x), f2u(throughput.y), f2u(throughput.z), seed);
+                    dest = launch_shadow(id, sun_ray, (uint32_t)hit_prim | (bounce << 12) | kHasSample | kShadow | (front_face ? 0u : kBackFace));
                 } else {
-                    st1(qA + id * 16u + 12u, 0u);        // the path ends without reaching the sky: E adds no light (hit_t != FLT_MAX)
+                    ++bounce;
+                    if ((int)bounce <= fp.bounce_limit) {                                  // :88 loop condition
+                        need_dir = true; dir_origin = origin; dir_normal = normal; dir_seed = seed; dir_bounce = bounce; dir_tries = 0;
+                        dir_thr = throughput;
+                    } else {
+                        st1(qA + id * 16u + 12u, 0u);    // the path ends without reaching the sky: E adds no light (hit_t != FLT_MAX)
+                        dest = QE;
+                    }
+                }
+            }
+            if (!SUN) draw_and_launch(true);
+        } else if (SUN && q == QS) {
+            // ============ S: the shadow traversal is over: sunlight, then the bounce direction and ray (RayGen.cuh:126-134) ============
+            if (active) {
+                const uint4 E = aux[id];
+                const uint4 A = ld4(qA + id * 16u);
+                const uint32_t W = ld1(qW + id * 4u);
+                if (!(W & kOccluded)) {
+                    float4 *const lp = aux_light + id;
+                    const f3 light = mk3(lp->x, lp->y, lp->z) + ld3(fp.suncol) * mk3(u2f(E.x), u2f(E.y), u2f(E.z));     // :126-127
+                    *lp = make_float4(light.x, light.y, light.z, 0.0f);
+                }
+                const uint32_t bounce = ((W >> 12) & 0xFFFFu) + 1u;
+                if ((int)bounce <= fp.bounce_limit) {                                      // :88 loop condition
+                    const f3 fn = fetch_face_normal((int)(W & 0xFFFu));
+                    need_dir = true; dir_origin = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); dir_normal = (W & kBackFace) ? (-1.f * fn) : fn;
+                    dir_seed = E.w; dir_bounce = bounce; dir_tries = 0;
+                } else {
+                    st1(qA + id * 16u + 12u, 0u);        // the path ends without reaching the sky
+                    st1(qW + id * 4u, kNoPrim | kHasSample);
                     dest = QE;
                 }
             }
-            draw_and_launch(true);
+            draw_and_launch(false);
         } else {
             // ============ E: finish the path, store its sample; deal a new sample, primary ray (RayGen.cuh:63-108,165-171) ============
             if (active) {
@@ -581,6 +641,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                     const uint4 B = ld4(qB + id * 16u);
                     const float hit_t = u2f(ld1(qA + id * 16u + 12u));
                     f3 light = mk3(0, 0, 0);
+                    if (SUN) { const float4 l = aux_light[id]; light = mk3(l.x, l.y, l.z); }
                     if (!(hit_t < FLT_MAX))                                                // miss: :99-108
                         light = light + sky_model(mk3(u2f(B.x), u2f(B.y), u2f(B.z)), ld3(fp.sky_color)) * mk3(u2f(E.x), u2f(E.y), u2f(E.z)) * fp.sky_intensity;
                     if (fp.tone_mapping) light = uncharted2_filmic(light, fp.exposure);    // :165-169 (wave-uniform branches)
@@ -626,6 +687,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                         dest = launch_ray(id, ray, 0u, fp.bounce_limit >= 0);
                         aux[id] = make_uint4(f2u(1.0f), f2u(1.0f), f2u(1.0f), seed);
                         aux_slot[id] = slot;
+                        if (SUN) aux_light[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         if (fp.bounce_limit < 0) st1(qA + id * 16u + 12u, 0u);            // RayGen.cuh:88: the loop body never runs, the sample is black
                     } else {
                         st1(qW + id * 4u, kNoPrim);         // a sample id outside the image (partial tile): the slot asks again
@@ -680,19 +742,20 @@ void path_pool_leaf_classes(const std::vector<LeafRange> &leaves, uint32_t out[3
 }
 
 bool path_pool_supports(const SceneView &sc, const FrameParams &fp, int bvh_depth, bool scene_has_alpha, size_t scene_lds_bytes) {
-    if (fp.render_mode != 0 || fp.enable_sunlight || scene_has_alpha) return false;       // lean paths only (so far)
+    (void)scene_has_alpha;
+    if (fp.render_mode != 0) return false;                                                // no debug views (wave_queue's general build)
     static const size_t scene_limit = std::getenv("DRT_POOL_SCENE_KB") ? (size_t)std::atoi(std::getenv("DRT_POOL_SCENE_KB")) * 1024 : kLdsSceneBytes;
     if (scene_lds_bytes > scene_limit || sc.n_tris >= 4095u || bvh_depth > 200) return false;
     if (fp.bounce_limit > 60000) return false;                                            // the bounce index is kept in 16 bits
     if (sc.root_ref == kNoNode) return false;
     // a pool of at least 256 paths has to fit the CU's LDS next to the scene copy (a very deep tree's stacks may not leave room)
     const uint32_t stack_entries = (uint32_t)std::max(bvh_depth, 1);
-    if (pool_layout(512u, 512u, stack_entries, pool_scene_bytes(sc), 0u).total > 160u * 1024u &&
-        (scene_lds_bytes > kLdsSceneBytes || pool_layout(256u, 256u, stack_entries, pool_scene_bytes(sc), 0u).total > 160u * 1024u)) return false;
+    if (pool_layout(512u, 512u, stack_entries, pool_scene_bytes(sc), 0u, (uint32_t)kNQ).total > 160u * 1024u &&
+        (scene_lds_bytes > kLdsSceneBytes || pool_layout(256u, 256u, stack_entries, pool_scene_bytes(sc), 0u, (uint32_t)kNQ).total > 160u * 1024u)) return false;
     return true;
 }
 
-hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_depth, const uint32_t t_class[3], const PoolTuning &tune,
+hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_depth, bool scene_has_alpha, const uint32_t t_class[3], const PoolTuning &tune,
                             PoolScratch &scratch, unsigned int *sample_counter, void *samples, unsigned int *status, int num_cus,
                             hipStream_t stream, const char **kernel_name, int *launch_shape) {
     if (fp.width == 0 || fp.local_rows == 0 || fp.n_frames == 0) return hipSuccess;
@@ -707,10 +770,11 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     const uint32_t cold_bytes = pool_cold_bytes(sc) <= (tune.cold_lds_kb >= 0 ? (uint32_t)tune.cold_lds_kb * 1024u : 4096u) ? pool_cold_bytes(sc) : 0u;
     // Workgroups per CU, pool size and threads: the most paths the CU's 160 KB of LDS hold (rings are sized to the next power of
     // two, so 1024 paths per workgroup is a sweet spot), then as many threads as paths, at most 24 waves per CU (16 in one workgroup).
+    const uint32_t n_rings = fp.enable_sunlight ? (uint32_t)kNQ : (uint32_t)kNQ - 1u;
     auto lds_for = [&](uint32_t paths, uint32_t &cap) {
         cap = 64;
         while (cap < paths) cap *= 2;
-        return pool_layout(paths, cap, stack_entries, scene_bytes, cold_bytes).total;
+        return pool_layout(paths, cap, stack_entries, scene_bytes, cold_bytes, n_rings).total;
     };
     uint32_t P = 0, ring_cap = 64;
     int groups = 1;
@@ -730,12 +794,18 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
         if (P == 0) return hipErrorInvalidValue;
         (void)lds_for(P, ring_cap);
     }
-    const PoolLayout lay = pool_layout(P, ring_cap, stack_entries, scene_bytes, cold_bytes);
+    const PoolLayout lay = pool_layout(P, ring_cap, stack_entries, scene_bytes, cold_bytes, n_rings);
     if (lay.total > 160u * 1024u) return hipErrorInvalidValue;
     int threads;
     if (env_threads > 0) threads = std::max(64, std::min(env_threads, kMaxPoolThreads) / 64 * 64);
     else threads = std::max(256, std::min<int>({ kMaxPoolThreads, (int)P / 64 * 64, 1536 / groups / 64 * 64 }));
-    auto kernel = tune.stats ? path_pool_kernel<true> : path_pool_kernel<false>;
+    const int flags = (tune.stats ? 1 : 0) | (fp.enable_sunlight ? 2 : 0) | (scene_has_alpha ? 4 : 0);
+    typedef void (*PoolKernel)(const SceneView, const FrameParams, const PoolParams, unsigned int *, float4 *);
+    static const PoolKernel kernels[8] = { path_pool_kernel<0>, path_pool_kernel<1>, path_pool_kernel<2>, path_pool_kernel<3>,
+                                           path_pool_kernel<4>, path_pool_kernel<5>, path_pool_kernel<6>, path_pool_kernel<7> };
+    static const char *const names[4] = { "path_pool<lean,lds-scene>", "path_pool<lean+sun,lds-scene>", "path_pool<lean+alpha,lds-scene>",
+                                          "path_pool<lean+alpha+sun,lds-scene>" };
+    const PoolKernel kernel = kernels[flags];
     if (lay.total > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total);
         if (e != hipSuccess) return e;
@@ -759,21 +829,25 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     // on the whole chip -- room 4K / 64 spp, two frames in flight: 998 ms per step with half a grid each, 757 with full grids)
     if (fp.frames_in_flight > 1 && tune.share_grid && n_chunks * 64ull < 64ull * (uint64_t)num_cus * per_cu * P)
         want = std::min<uint64_t>(want, std::max<uint64_t>(1, ((uint64_t)num_cus * per_cu + fp.frames_in_flight - 1) / (uint64_t)fp.frames_in_flight));
-    // the part of the path state that lives in HBM: 20 bytes per pool slot of every workgroup
+    // the part of the path state that lives in HBM: 36 bytes per pool slot of every workgroup (16 of them used by sunlight only)
     const size_t slots = (size_t)num_cus * per_cu * P;
     if (slots > scratch.slots) {
         if (scratch.aux) (void)hipFree(scratch.aux);
         if (scratch.aux_slot) (void)hipFree(scratch.aux_slot);
-        scratch.aux = nullptr; scratch.aux_slot = nullptr; scratch.slots = 0;
+        if (scratch.aux_light) (void)hipFree(scratch.aux_light);
+        scratch.aux = nullptr; scratch.aux_slot = nullptr; scratch.aux_light = nullptr; scratch.slots = 0;
         hipError_t ea = hipMalloc(&scratch.aux, slots * 16);
         if (ea != hipSuccess) return ea;
         ea = hipMalloc(&scratch.aux_slot, slots * 4);
         if (ea != hipSuccess) return ea;
+        ea = hipMalloc(&scratch.aux_light, slots * 16);
+        if (ea != hipSuccess) return ea;
         scratch.slots = slots;
     }
     pp.aux = static_cast<uint4 *>(scratch.aux); pp.aux_slot = static_cast<uint32_t *>(scratch.aux_slot);
+    pp.aux_light = static_cast<float4 *>(scratch.aux_light);
     hipError_t e = hipSuccess;                 // (*sample_counter is zero: drt_capi.cpp hands out zeroed counters)
-    if (kernel_name) *kernel_name = "path_pool<lean,lds-scene>";
+    if (kernel_name) *kernel_name = names[flags >> 1];
     if (launch_shape) { launch_shape[0] = (int)stack_entries; launch_shape[1] = per_cu; launch_shape[2] = (int)(lay.total / 1024); launch_shape[3] = threads; launch_shape[4] = (int)P; }
     FrameParams fq = fp;
     fq.inline_resolve = fp.n_frames == 1 ? 1 : 0;

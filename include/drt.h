@@ -277,9 +277,10 @@ int           drt_debug_hash_cycles(int32_t device, uint32_t max_len, uint32_t *
  * JSON text: one plan per (kernel, scene shape, view class) with its candidates, their trials and best ns per sample, and
  * the index of the one kept (-1 = still measuring).  All candidates compute the same image. */
 int           drt_debug_wave_queue_plans(const drt_renderer *r, char *buf, size_t cap);
-/* path_pool kernel statistics of a renderer created with DRT_POOL_STATS=1 in the environment: per queue (N, T0..T3, B, E, R)
- * {batches, paths served, shader-clock ticks}, then ticks spent claiming, idle polls, lost claims, wave ticks. */
-int           drt_debug_pool_stats(drt_renderer *r, uint64_t out[32], int32_t reset);
+/* path_pool kernel statistics of a renderer created with DRT_POOL_STATS=1 in the environment: per queue (N, T0..T3, B, E, R, S)
+ * {batches, paths served, shader-clock ticks}, then ticks spent claiming, idle polls, lost claims, wave ticks, claims given up,
+ * their ticks, idle ticks. */
+int           drt_debug_pool_stats(drt_renderer *r, uint64_t out[40], int32_t reset);
 uint32_t      drt_shard_rows(uint32_t height, uint32_t stripe_rows, uint32_t rank, uint32_t world);
 
 #ifdef __cplusplus

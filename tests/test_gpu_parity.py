@@ -289,7 +289,7 @@ def test_external_buffers_and_stream():
     compare(rgba.cpu().numpy(), ref, "external buffers")
 
 
-def _render_with_env(env, name, W, H, frames, depth):
+def _render_with_env(env, name, W, H, frames, depth, **settings):
     import os
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
@@ -303,7 +303,7 @@ def _render_with_env(env, name, W, H, frames, depth):
                 os.environ[k] = v
     sc, osc = make_pair(name)
     cam, ocam = cameras(name)
-    s, o = settings_pair(ray_bounce_limit=depth)
+    s, o = settings_pair(ray_bounce_limit=depth, **settings)
     r.m_RendererSettings = s
     r.ResizeBuffer(W, H)
     r.RenderBatch(cam, sc, frames)
@@ -664,10 +664,25 @@ def test_path_pool_scheduling_knobs_do_not_change_the_image(env):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["path_pool", "wave_queue"])
+@pytest.mark.parametrize("name,W,H,frames,depth,sun", [("cornell_box", 128, 72, 2, 5, 1), ("room", 96, 54, 2, 8, 1), ("sunshadow_test", 128, 72, 2, 3, 1),
+                                                        ("uv_texture_test", 128, 72, 2, 5, 0), ("uv_texture_test", 96, 54, 2, 4, 1),
+                                                        ("cornell_box", 64, 36, 1, 0, 1)])
+def test_sunlight_and_alpha_cutouts_on_both_tracing_kernels(kernel, name, W, H, frames, depth, sun):
+    """The sun's shadow ray (RayGen.cuh:124-128: RayTest, any accepted hit occludes) and the alpha test of AnyHit.cuh:8-28 in
+    path_pool (shadow traversals ride the same N / T queues, S = the rest of the shading) and in wave_queue: the oracle's bits."""
+    r, ref, ref_acc = _render_with_env({"DRT_KERNEL": kernel}, name, W, H, frames, depth, enableSunlight=sun)
+    assert r.kernelInfo().startswith(kernel), r.kernelInfo()
+    want = "lean" + ("+alpha" if name == "uv_texture_test" else "") + ("+sun" if sun else "")
+    assert "<%s," % want in r.kernelInfo(), r.kernelInfo()
+    compare(r.GetRenderTargetImage(), ref, "%s %s sun=%d" % (kernel, name, sun))
+    compare(r.GetAccumulationBuffer(), ref_acc, "%s %s accum" % (kernel, name))
+
+
+@pytest.mark.gpu
 def test_path_pool_falls_back_where_it_does_not_apply():
-    """Sunlight, debug views, alpha textures, scenes too big for LDS and the counting build stay on wave_queue."""
-    for name, kw in (("cornell_box", dict(enableSunlight=1)), ("cornell_box", dict(RenderMode=1, DebugMode=1)), ("uv_texture_test", {}),
-                     ("suzanne_plane", {})):
+    """Debug views, scenes too big for LDS and the counting build stay on wave_queue."""
+    for name, kw in (("cornell_box", dict(RenderMode=1, DebugMode=1)), ("suzanne_plane", {}), ("cs16_dust", dict(enableSunlight=1))):
         sc, osc = make_pair(name)
         cam, ocam = cameras(name)
         s, o = settings_pair(ray_bounce_limit=3, **kw)

@@ -24,11 +24,11 @@ ns = W * H * frames
 print(r.kernelInfo(), "%.3f ms (stats build)" % ms)
 wt = st["wave_ticks"]
 tot_b = 0
-for q in ("N", "T0", "T1", "T2", "T3", "B", "E", "R"):
+for q in ("N", "T0", "T1", "T2", "T3", "B", "E", "R", "S"):
     b_, l_, t_ = st[q]
     tot_b += b_
     print("  %-3s batches/64 samples %6.3f  fill %5.1f  ticks/batch %7.0f  share of wave time %5.1f%%" % (q, b_ / ns * 64, l_, t_ / max(b_, 1), 100.0 * t_ / wt))
-print("  claims given up after 4 attempts: %d (%.2f per batch), %.1f%% of wave time; waiting for company / idle: %.1f%% of wave time" % (
+print("  claims given up: %d (%.2f per batch), %.1f%% of wave time; waiting for company / idle: %.1f%% of wave time" % (
     st["failed_claims"], st["failed_claims"] / max(tot_b, 1), 100.0 * st["failed_claim_ticks"] / wt, 100.0 * st["idle_ticks"] / wt))
 print("  claim: %.1f%% of wave time, %.0f ticks per batch; idle polls %d (%.2f per batch); lost claims %d" % (
     100.0 * st["claim_ticks"] / wt, st["claim_ticks"] / max(tot_b, 1), st["idle_polls"], st["idle_polls"] / max(tot_b, 1), st["lost_claims"]))
