@@ -131,7 +131,7 @@ __host__ __device__ inline uint32_t pool_cold_bytes(const SceneView &sc) { retur
 struct PoolParams {
     uint32_t P;                // paths in the pool (multiple of 64)
     uint32_t ring_cap;         // entries per ring: power of two >= P
-    uint32_t stack_entries;    // BVH depth
+    uint32_t stack_entries;    // BVH levels - 1
     uint32_t total_samples;    // n_chunks * 64 (sample ids beyond the image edge are skipped)
     uint32_t n_chunks, tiles_x;
     uint32_t t_class[3];       // leaf step counts (two triangles per step) up to t_class[i] wait in queue T<i>; larger ones in T3
@@ -749,7 +749,7 @@ bool path_pool_supports(const SceneView &sc, const FrameParams &fp, int bvh_dept
     if (fp.bounce_limit > 60000) return false;                                            // the bounce index is kept in 16 bits
     if (sc.root_ref == kNoNode) return false;
     // a pool of at least 256 paths has to fit the CU's LDS next to the scene copy (a very deep tree's stacks may not leave room)
-    const uint32_t stack_entries = (uint32_t)std::max(bvh_depth, 1);
+    const uint32_t stack_entries = (uint32_t)std::max(bvh_depth - 1, 1);
     if (pool_layout(512u, 512u, stack_entries, pool_scene_bytes(sc), 0u, (uint32_t)kNQ).total > 160u * 1024u &&
         (scene_lds_bytes > kLdsSceneBytes || pool_layout(256u, 256u, stack_entries, pool_scene_bytes(sc), 0u, (uint32_t)kNQ).total > 160u * 1024u)) return false;
     return true;
@@ -763,7 +763,11 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     const uint32_t tiles_x = (fp.width + 7) / 8, tiles_y = (fp.local_rows + 7) / 8;
     const uint64_t n_chunks = (uint64_t)tiles_x * tiles_y * fp.n_frames;
     if (n_chunks * 64ull > 0xFFF00000ull) return hipErrorInvalidValue;
-    const uint32_t stack_entries = (uint32_t)std::max(bvh_depth, 1);
+    // Stack slots: the far siblings of the nodes on the way down, one per level below the root -- the near child of a visit stays
+    // in registers and is spilled only where it is an interior node, so never more than levels - 1 entries.  (Smaller entries were
+    // tried on room, where 64 more paths in the pool are worth 3-5 %: 6 bytes {distance, parent << 1 | which child} cost 3.5 % at
+    // equal pool size and end level at 1408 paths against 1216; 2 bytes with the distance computed again at the pop cost 7 %.)
+    const uint32_t stack_entries = (uint32_t)std::max(bvh_depth - 1, 1);
     const uint32_t scene_bytes = pool_scene_bytes(sc);
     // the shading records go to LDS too when they are small (cornell: 1.2 KB): B's load chain triangle -> material ->
     // texture header then runs through LDS instead of three dependent HBM / L2 round trips

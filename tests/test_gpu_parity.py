@@ -512,7 +512,8 @@ def test_edge_case_scenes_and_frame_sizes(renderer):
     for kw in ({}, {"enableSunlight": 1}):
         img, ref = _render_both(renderer, sc, osc, (-3.0, 0.1, 0.2), (1.0, 0.02, -0.03), 64, 36, 2, ray_bounce_limit=3, **kw)
         compare(img, ref, "degenerate %d-level tree %r (%s)" % (sc.bvh_depth, kw, renderer.kernelInfo()))
-        assert "stack=%d" % sc.bvh_depth in renderer.kernelInfo()
+        # (path_pool keeps the near child of a visit in registers: one stack slot per level below the root)
+        assert "stack=%d " % (sc.bvh_depth - 1 if renderer.kernelInfo().startswith("path_pool") else sc.bvh_depth) in renderer.kernelInfo()
     # (3) long paths: the closed cornell box with 32 bounces
     sc, osc = make_pair("cornell_box")
     cam, ocam = cameras("cornell_box")
@@ -597,8 +598,8 @@ def test_kernel_packaging_is_measured_not_guessed():
     5.1).  They all compute the same image, so the renderer times each on its first big launches and keeps the fastest; scenes
     whose traversal data fits LDS go to path_pool.  Checked: the image is the oracle's whatever is being tried, every candidate
     gets its trials, and the one kept is the best measured (within 2 %)."""
-    expect = {"cornell_box": "path_pool<lean,lds-scene> stack=3 wg/CU=2 ",             # small LDS scene, lean paths: the path pool, two pools per CU
-              "room": "path_pool<lean,lds-scene> stack=8 wg/CU=1 ",                    # 17.6 KB LDS scene, 8-level tree: one pool per CU
+    expect = {"cornell_box": "path_pool<lean,lds-scene> stack=2 wg/CU=2 ",             # small LDS scene, lean paths: the path pool, two pools per CU
+              "room": "path_pool<lean,lds-scene> stack=7 wg/CU=1 ",                    # 17.6 KB LDS scene, 8-level tree: one pool per CU
               "cs16_dust": "wave_queue<lean,hbm-scene> stack=16",                      # deep tree from HBM: 8- or 6-byte stack entries, 2 or 3 triangles per step
               "suzanne_plane": "wave_queue<lean,hbm-scene> stack=10"}
     r = drt.Renderer(0)
