@@ -124,7 +124,7 @@ __host__ __device__ inline PoolLayout pool_layout(uint32_t P, uint32_t ring_cap,
     return l;
 }
 constexpr uint32_t kCtrlLive = 80, kCtrlAbort = 84, kCtrlExhausted = 88;      // (the pairs of lanes 10 and 11 of the control read)
-__host__ __device__ inline uint32_t pool_scene_bytes(const SceneView &sc) { return sc.n_inner * 64u + sc.n_tris * 48u + ((sc.n_leaves * 8u + 15u) & ~15u); }
+__host__ __device__ inline uint32_t pool_scene_bytes(const SceneView &sc) { return sc.n_inner * 64u + sc.n_tris * 48u; }   // (leaf ranges ride in the references)
 __host__ __device__ inline uint32_t pool_cold_bytes(const SceneView &sc) { return sc.n_tris * 32u + sc.n_mats * 16u + sc.n_texs * 16u; }
 
 // What the host decides per launch (next to FrameParams)
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds_raw);      // low 32 bits of the flat address = LDS offset
     const uint32_t ctrl = lds_base + lay.ctrl, rings = lds_base + lay.rings, stack = lds_base + lay.stack;
     const uint32_t qA = lds_base + lay.quads, qB = qA + P * 16u, qW = lds_base + lay.words;
-    const uint32_t lds_inner = lds_base + lay.scene, lds_hot = lds_inner + sc.n_inner * 64u, lds_leaf = lds_hot + sc.n_tris * 48u;
+    const uint32_t lds_inner = lds_base + lay.scene, lds_hot = lds_inner + sc.n_inner * 64u;
     const uint32_t lds_cold = lds_base + lay.cold, lds_mats = lds_cold + sc.n_tris * 32u, lds_texs = lds_mats + sc.n_mats * 16u;
     uint4 *const aux = pp.aux + (size_t)blockIdx.x * P;
     uint32_t *const aux_slot = pp.aux_slot + (size_t)blockIdx.x * P;
@@ -188,7 +188,6 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             st4(lds_inner + i * 16u, v);
         }
         for (uint32_t i = tid; i < sc.n_tris * 3u; i += wg) st4(lds_hot + i * 16u, g_hot[i]);
-        for (uint32_t i = tid; i < sc.n_leaves; i += wg) st2(lds_leaf + i * 8u, make_uint2((uint32_t)sc.leaves[i].start, (uint32_t)sc.leaves[i].count));
         if (cold_lds) {
             const uint4 *g_cold = reinterpret_cast<const uint4 *>(sc.tri_cold);
             const uint4 *g_mats = reinterpret_cast<const uint4 *>(sc.mats);
@@ -767,6 +766,9 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     // in registers and is spilled only where it is an interior node, so never more than levels - 1 entries.  (Smaller entries were
     // tried on room, where 64 more paths in the pool are worth 3-5 %: 6 bytes {distance, parent << 1 | which child} cost 3.5 % at
     // equal pool size and end level at 1408 paths against 1216; 2 bytes with the distance computed again at the pop cost 7 %.)
+    // (Rings of exactly P entries instead of the next power of two -- positions counted modulo a multiple of P, slot = position
+    // mod P by multiplication -- were tried too: room's pool grows from 1216 to 1344 paths, and the extra arithmetic in every claim
+    // and push costs the 3 % that buys.)
     const uint32_t stack_entries = (uint32_t)std::max(bvh_depth - 1, 1);
     const uint32_t scene_bytes = pool_scene_bytes(sc);
     // the shading records go to LDS too when they are small (cornell: 1.2 KB): B's load chain triangle -> material ->
