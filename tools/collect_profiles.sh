@@ -36,4 +36,9 @@ for s in 0/2 0/4 0/8; do python3 $R/bench.py --emulate-shard $s --cpu-seconds 0 
 python3 $R/tools/pool_stats.py cornell_box 1920 1080 8 8 > $O/${TAG}_pool_stats_cornell.txt 2>&1
 python3 $R/tools/pool_stats.py room 1920 1080 4 16 > $O/${TAG}_pool_stats_room.txt 2>&1
 python3 $R/tools/small_launches.py > $O/${TAG}_small_launches.txt 2>&1
+# the issue costs the roofline prices instructions with (built beforehand: see the header of tools/microbench/valu_issue.hip)
+if [ -x $R/tools/microbench/valu_issue_noslp ]; then
+  (echo "== hipcc -O3 -fno-slp-vectorize (as the library is built): single instructions"; $R/tools/microbench/valu_issue_noslp
+   echo "== hipcc -O3: the independent adds / multiplies / fmas of the first rows are packed into v_pk_*_f32"; $R/tools/microbench/valu_issue) > $O/${TAG}_valu_issue.txt 2>&1
+fi
 ls -la $O

@@ -1,5 +1,8 @@
 // valu_issue.hip -- how many wave64 VALU instructions per cycle one gfx950 SIMD sustains, by instruction kind and by
-// waves per SIMD.  Standalone: hipcc --offload-arch=gfx950 -O3 -o valu_issue valu_issue.hip && ./valu_issue
+// waves per SIMD.  Standalone: hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o valu_issue_noslp valu_issue.hip && ./valu_issue_noslp
+// (-fno-slp-vectorize as the library is built: a plain -O3 build packs the independent adds / multiplies / fmas of the first rows into
+// v_pk_*_f32 -- 4 cycles for two operations per lane, the same rate for add and mul, twice the rate for fma; profiles/r02_valu_issue.txt
+// holds both builds' output)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
