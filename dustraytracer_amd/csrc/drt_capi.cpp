@@ -578,6 +578,11 @@ static int upload_scene(drt_renderer *r, const drt_scene *scene) {
     r->bvh_depth = ps.depth;
     r->scene_has_alpha = ps.any_alpha_texture;
     path_pool_leaf_classes(ps.leaves, r->pool_t_class);
+    if (const char *e = std::getenv("DRT_POOL_T_CLASSES")) {              // experiments: "a,b,c" = upper step counts of T0, T1, T2
+        unsigned a0 = 0, a1 = 0, a2 = 0;
+        if (std::sscanf(e, "%u,%u,%u", &a0, &a1, &a2) == 3) { r->pool_t_class[0] = a0; r->pool_t_class[1] = a1; r->pool_t_class[2] = a2; }
+    }
+    if (std::getenv("DRT_POOL_VERBOSE")) std::fprintf(stderr, "path_pool leaf classes: %u %u %u\n", r->pool_t_class[0], r->pool_t_class[1], r->pool_t_class[2]);
     r->uploaded_scene = scene;
     r->uploaded_revision = scene->host.revision;
     return DRT_OK;
