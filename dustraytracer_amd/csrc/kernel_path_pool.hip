@@ -205,16 +205,27 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         __syncthreads();
     }
 
+#ifndef DRT_POOL_GLOBAL_SCENE
+#define DRT_POOL_GLOBAL_SCENE 0          // experiment (tools/experiments/r02): 1 = traversal data read from global memory, LDS copy unused
+#endif
     auto fetch_tri = [&](int i) -> TriTest {
         const uint32_t q = lds_hot + __umul24((uint32_t)i, 48u);
-        const uint4 a = ld4(q), b = ld4(q + 16); const uint32_t c = ld1(q + 32);
+        uint4 a, b; uint32_t c;
+        if (DRT_POOL_GLOBAL_SCENE) {
+            const uint4 *g = reinterpret_cast<const uint4 *>(sc.tri_hot) + (size_t)i * 3;
+            a = g[0]; b = g[1]; c = reinterpret_cast<const uint32_t *>(g)[8];
+        } else { a = ld4(q); b = ld4(q + 16); c = ld1(q + 32); }
         TriTest t;
         t.v0 = mk3(u2f(a.x), u2f(a.y), u2f(a.z)); t.e1 = mk3(u2f(a.w), u2f(b.x), u2f(b.y)); t.e2 = mk3(u2f(b.z), u2f(b.w), u2f(c));
         return t;
     };
     auto fetch_children = [&](uint32_t index) -> ChildPair {
         const uint32_t q = lds_inner + index * 64u;
-        const uint4 a = ld4(q), b = ld4(q + 16), c = ld4(q + 32); const uint2 r = ld2(q + 48);
+        uint4 a, b, c; uint2 r;
+        if (DRT_POOL_GLOBAL_SCENE) {
+            const uint4 *g = reinterpret_cast<const uint4 *>(sc.inner) + (size_t)index * 4;
+            a = g[0]; b = g[1]; c = g[2]; r = *reinterpret_cast<const uint2 *>(g + 3);
+        } else { a = ld4(q); b = ld4(q + 16); c = ld4(q + 32); r = ld2(q + 48); }
         ChildPair p;
         p.min1 = mk3(u2f(a.x), u2f(a.y), u2f(a.z)); p.max1 = mk3(u2f(a.w), u2f(b.x), u2f(b.y));
         p.min2 = mk3(u2f(b.z), u2f(b.w), u2f(c.x)); p.max2 = mk3(u2f(c.y), u2f(c.z), u2f(c.w));
@@ -248,6 +259,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     };
     // leaf -> (first triangle, end) packed with the stack height, and the T queue of its size class
     auto leaf_state = [&](uint32_t leaf_ref, int sp, uint32_t &packed) -> int {          // leaf_ref = count << 12 | first triangle
+        if (DRT_POOL_GLOBAL_SCENE) { const LeafRange lr = sc.leaves[leaf_ref]; leaf_ref = ((uint32_t)lr.count << 12) | (uint32_t)lr.start; }
         const uint32_t cur = leaf_ref & 0xFFFu, count = leaf_ref >> 12;
         packed = cur | ((cur + count) << 12) | ((uint32_t)sp << 24);
         const uint32_t steps = (count + 1u) >> 1;
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     const f3 root_min = ld3(sc.root_min), root_max = ld3(sc.root_max);
     // TraceRay.cu:15-20 + BVHTraversal.cuh:22-26,38: the root goes on the stack with its slab distance when -1 < d < FLT_MAX
     uint32_t root_ref = sc.root_ref;                      // (a one-leaf scene: the same self-describing form as the staged records)
-    if (root_ref != kNoNode && (root_ref & kLeafBit)) { const LeafRange lr = sc.leaves[root_ref & ~kLeafBit]; root_ref = kLeafBit | ((uint32_t)lr.count << 12) | (uint32_t)lr.start; }
+    if (!DRT_POOL_GLOBAL_SCENE && root_ref != kNoNode && (root_ref & kLeafBit)) { const LeafRange lr = sc.leaves[root_ref & ~kLeafBit]; root_ref = kLeafBit | ((uint32_t)lr.count << 12) | (uint32_t)lr.start; }
     auto begin_closest = [&](const Ray &ray, uint2 &top) -> bool {
         if (sc.root_ref == kNoNode) return false;
         const float d = slab_intersect(root_min, root_max, ray);

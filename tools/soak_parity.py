@@ -10,7 +10,10 @@ from tests.scenes import SCENES, scene_path
 CASES = [("cornell_box", 1920, 1080, 64, 8, {}), ("cs16_dust", 1920, 1080, 8, 5, {}), ("mc_transparency", 1920, 1080, 16, 5, {}),
          ("suzanne_plane", 3840, 2160, 8, 4, {}), ("sunshadow_test", 1920, 1080, 8, 3, dict(enableSunlight=1)),
          ("room", 1920, 1080, 8, 16, {}), ("lightweight_rt", 1920, 1080, 16, 6, dict(enableSunlight=1)),
-         ("dense_monkey", 1920, 1080, 8, 8, dict(tone_mapping=0))]
+         ("dense_monkey", 1920, 1080, 8, 8, dict(tone_mapping=0)),
+         # round 2: sunlight and cut-outs on path_pool
+         ("cornell_box", 1920, 1080, 8, 8, dict(enableSunlight=1)), ("room", 1920, 1080, 4, 16, dict(enableSunlight=1)),
+         ("uv_texture_test", 1920, 1080, 8, 5, dict(enableSunlight=1)), ("uv_texture_test", 1920, 1080, 8, 5, {})]
 if len(sys.argv) > 1 and sys.argv[1] == "c5":           # BASELINE config 5 whole: 531 M samples, several minutes of oracle time
     CASES = [("room", 3840, 2160, 64, 16, {})]
 names = {"enableSunlight": "enable_sunlight"}
