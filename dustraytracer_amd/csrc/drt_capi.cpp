@@ -693,9 +693,10 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
                 r->counters_used = 0;
             }
             unsigned int *const queue_head = r->tile_counter + r->counters_used++;
+            bool pool_hbm_scene = false;
             if (r->use_path_pool && !r->counting && !material_ext &&
-                path_pool_supports(r->view, fp, r->bvh_depth, r->scene_has_alpha, wave_queue_scene_lds_bytes(r->view)))
-                HIP_TRY(launch_path_pool(r->view, fp, r->bvh_depth, r->scene_has_alpha, r->pool_t_class, r->pool_tuning, r->pool_scratch, queue_head, r->samples, r->pool_status,
+                path_pool_supports(r->view, fp, r->bvh_depth, wave_queue_scene_lds_bytes(r->view), &pool_hbm_scene))
+                HIP_TRY(launch_path_pool(r->view, fp, r->bvh_depth, r->scene_has_alpha, pool_hbm_scene, r->pool_t_class, r->pool_tuning, r->pool_scratch, queue_head, r->samples, r->pool_status,
                                          r->num_cus, r->stream, &r->kernel_name, r->launch_shape));
             else
             HIP_TRY(launch_wave_queue(r->view, fp, r->bvh_depth, r->counting ? 2 : (material_ext ? 1 : 0), r->scene_has_alpha, queue_head,

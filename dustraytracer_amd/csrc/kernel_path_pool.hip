@@ -60,6 +60,8 @@ DRT_DEV uint32_t ld1(uint32_t off) { return *(PP_LDS(const uint32_t) *)off; }
 DRT_DEV void st4(uint32_t off, uint4 v) { pp_u32x4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; *(PP_LDS(pp_u32x4) *)off = w; }
 DRT_DEV void st2(uint32_t off, uint2 v) { pp_u32x2 w; w.x = v.x; w.y = v.y; *(PP_LDS(pp_u32x2) *)off = w; }
 DRT_DEV void st1(uint32_t off, uint32_t v) { *(PP_LDS(uint32_t) *)off = v; }
+DRT_DEV uint32_t ld_u16(uint32_t off) { return *(PP_LDS(const unsigned short) *)off; }
+DRT_DEV void st_u16(uint32_t off, uint32_t v) { *(PP_LDS(unsigned short) *)off = (unsigned short)v; }
 // control words and ring entries are shared between waves: relaxed atomics (never cached in registers), workgroup scope
 DRT_DEV uint32_t ld1_shared(uint32_t off) { return __hip_atomic_load((PP_LDS(uint32_t) *)off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 DRT_DEV void st1_shared(uint32_t off, uint32_t v) { __hip_atomic_store((PP_LDS(uint32_t) *)off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -88,6 +90,8 @@ __device__ inline uint32_t ld1(uint32_t) { return 0; }
 __device__ inline void st4(uint32_t, uint4) {}
 __device__ inline void st2(uint32_t, uint2) {}
 __device__ inline void st1(uint32_t, uint32_t) {}
+__device__ inline uint32_t ld_u16(uint32_t) { return 0; }
+__device__ inline void st_u16(uint32_t, uint32_t) {}
 __device__ inline uint32_t ld1_shared(uint32_t) { return 0; }
 __device__ inline void st1_shared(uint32_t, uint32_t) {}
 __device__ inline uint2 ld2_shared(uint32_t) { return make_uint2(0, 0); }
@@ -111,14 +115,16 @@ struct PoolLayout {
     uint32_t ctrl, rings, quads, words, stack, scene, cold, total;      // byte offsets; total = bytes needed
 };
 __host__ __device__ inline PoolLayout pool_layout(uint32_t P, uint32_t ring_cap, uint32_t stack_entries, uint32_t scene_bytes, uint32_t cold_bytes,
-                                                  uint32_t n_rings = (uint32_t)kNQ - 1u /* S's ring exists in sunlight builds only */) {
+                                                  uint32_t n_rings = (uint32_t)kNQ - 1u /* S's ring exists in sunlight builds only */,
+                                                  uint32_t word_bytes = 4u /* 16 in the hbm-scene build: {meta, hit triangle, leaf end, -} */,
+                                                  uint32_t stack_entry_bytes = 8u /* 6 in the hbm-scene build */) {
     PoolLayout l;
     l.ctrl = 0;                                     // head/tail pairs of the kNQ queues (8 B each), then {live, abort}, {exhausted, -}
     l.rings = 128;
     l.quads = l.rings + n_rings * ring_cap * 2u;
     l.words = l.quads + 2u * P * 16u;
-    l.stack = l.words + P * 4u;
-    l.scene = (l.stack + stack_entries * P * 8u + 15u) & ~15u;
+    l.stack = l.words + P * word_bytes;
+    l.scene = (l.stack + stack_entries * P * stack_entry_bytes + 15u) & ~15u;
     l.cold = l.scene + scene_bytes;
     l.total = l.cold + cold_bytes;
     return l;
@@ -148,11 +154,15 @@ struct PoolParams {
     unsigned long long *stats; // STATS build: per queue {batches, lanes, ticks} (3 x kNQ), then claim ticks, idle polls, lost claims, wave ticks
 };
 
-// FLAGS: 1 = statistics, 2 = sunlight (a shadow ray per shaded hit, RayGen.cuh:124-128), 4 = alpha cut-outs (AnyHit.cuh:8-28)
+// FLAGS: 1 = statistics, 2 = sunlight (a shadow ray per shaded hit, RayGen.cuh:124-128), 4 = alpha cut-outs (AnyHit.cuh:8-28),
+// 8 = hbm-scene: the traversal data is too big for LDS and is read from global memory (L2); the pool -- path state, stacks, queues --
+// is the same, with 32-bit triangle indices: word W becomes a quad {meta = bounce | stack height << 16 | flags, hit triangle, leaf end, -}
+// and B's fourth word the current triangle
 template <int FLAGS>
 __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneView sc, const FrameParams fp, const PoolParams pp,
                                                                     unsigned int *sample_counter, float4 *samples) {
-    constexpr bool STATS = (FLAGS & 1) != 0, SUN = (FLAGS & 2) != 0, ALPHA = (FLAGS & 4) != 0;
+    constexpr bool STATS = (FLAGS & 1) != 0, SUN = (FLAGS & 2) != 0, ALPHA = (FLAGS & 4) != 0, HBM = (FLAGS & 8) != 0;
+    constexpr uint32_t kWordBytes = HBM ? 16u : 4u, kStackEntryBytes = HBM ? 6u : 8u;
     extern __shared__ uint4 lds_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     const uint32_t ring_mask = pp.ring_cap - 1u;
     const bool cold_lds = pp.cold_in_lds != 0;
     constexpr uint32_t kRings = SUN ? (uint32_t)kNQ : (uint32_t)kNQ - 1u;
-    const PoolLayout lay = pool_layout(P, pp.ring_cap, pp.stack_entries, pool_scene_bytes(sc), cold_lds ? pool_cold_bytes(sc) : 0u, kRings);
+    const PoolLayout lay = pool_layout(P, pp.ring_cap, pp.stack_entries, HBM ? 0u : pool_scene_bytes(sc), cold_lds ? pool_cold_bytes(sc) : 0u, kRings, kWordBytes, kStackEntryBytes);
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds_raw);      // low 32 bits of the flat address = LDS offset
     const uint32_t ctrl = lds_base + lay.ctrl, rings = lds_base + lay.rings, stack = lds_base + lay.stack;
     const uint32_t qA = lds_base + lay.quads, qB = qA + P * 16u, qW = lds_base + lay.words;
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         const uint4 *g_hot = reinterpret_cast<const uint4 *>(sc.tri_hot);
         // (leaf references are rewritten while the records are staged: kLeafBit | count << 12 | first triangle -- reaching a leaf
         // then costs no LeafRange load; n_tris < 4096 is what path_pool_supports guarantees)
-        for (uint32_t i = tid; i < sc.n_inner * 4u; i += wg) {
+        for (uint32_t i = tid; !HBM && i < sc.n_inner * 4u; i += wg) {
             uint4 v = g_inner[i];
             if ((i & 3u) == 3u) {
                 if (v.x & kLeafBit) { const LeafRange lr = sc.leaves[v.x & ~kLeafBit]; v.x = kLeafBit | ((uint32_t)lr.count << 12) | (uint32_t)lr.start; }
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             }
             st4(lds_inner + i * 16u, v);
         }
-        for (uint32_t i = tid; i < sc.n_tris * 3u; i += wg) st4(lds_hot + i * 16u, g_hot[i]);
+        for (uint32_t i = tid; !HBM && i < sc.n_tris * 3u; i += wg) st4(lds_hot + i * 16u, g_hot[i]);
         if (cold_lds) {
             const uint4 *g_cold = reinterpret_cast<const uint4 *>(sc.tri_cold);
             const uint4 *g_mats = reinterpret_cast<const uint4 *>(sc.mats);
@@ -198,20 +208,31 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         }
         for (uint32_t i = tid; i < kRings * pp.ring_cap; i += wg) st_id(rings + i * 2u, kEmptyId);
         for (uint32_t i = tid; i < 32u; i += wg) st1(ctrl + i * 4u, 0u);
-        for (uint32_t i = tid; i < P; i += wg) st1(qW + i * 4u, kNoPrim);               // no sample yet
+        for (uint32_t i = tid; i < P; i += wg) st1(qW + i * kWordBytes, HBM ? 0u : kNoPrim);       // no sample yet
         __syncthreads();
         for (uint32_t i = tid; i < P; i += wg) st_id(rings + ((uint32_t)QE * pp.ring_cap + i) * 2u, i);
         if (tid == 0) { st1(ctrl + QE * 8u + 4u, P); st1(ctrl + kCtrlLive, P); }
         __syncthreads();
     }
 
-#ifndef DRT_POOL_GLOBAL_SCENE
-#define DRT_POOL_GLOBAL_SCENE 0          // experiment (tools/experiments/r02): 1 = traversal data read from global memory, LDS copy unused
-#endif
+    // ---- the path's words: meta (flags, bounce index; + hit triangle in the lds-scene build, + stack height in the hbm-scene build) ----
+    auto meta_at = [&](uint32_t id) -> uint32_t { return qW + id * kWordBytes; };
+    auto bounce_of = [&](uint32_t meta) -> uint32_t { return HBM ? (meta & 0xFFFFu) : ((meta >> 12) & 0xFFFFu); };
+    auto prim_of = [&](uint32_t id, uint32_t meta) -> uint32_t { return HBM ? ld1(meta_at(id) + 4u) : (meta & 0xFFFu); };
+    // (prim: only the lds-scene build keeps it in this word; the hbm-scene build's stays where T wrote it)
+    auto make_meta = [&](uint32_t prim, uint32_t bounce, uint32_t flags) -> uint32_t { return HBM ? (bounce | flags) : (prim | (bounce << 12) | flags); };
+    // what N and T leave behind: the leaf the path stands on (if any) and its stack height
+    auto store_trav = [&](uint32_t id, int sp, uint32_t cur, uint32_t end, uint32_t meta) {
+        if (HBM) {
+            st1(qB + id * 16u + 12u, cur);
+            st1(meta_at(id) + 8u, end);
+            st1(meta_at(id), (meta & ~0x00FF0000u) | ((uint32_t)sp << 16));
+        } else st1(qB + id * 16u + 12u, cur | (end << 12) | ((uint32_t)sp << 24));
+    };
     auto fetch_tri = [&](int i) -> TriTest {
         const uint32_t q = lds_hot + __umul24((uint32_t)i, 48u);
         uint4 a, b; uint32_t c;
-        if (DRT_POOL_GLOBAL_SCENE) {
+        if (HBM) {
             const uint4 *g = reinterpret_cast<const uint4 *>(sc.tri_hot) + (size_t)i * 3;
             a = g[0]; b = g[1]; c = reinterpret_cast<const uint32_t *>(g)[8];
         } else { a = ld4(q); b = ld4(q + 16); c = ld1(q + 32); }
@@ -222,7 +243,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     auto fetch_children = [&](uint32_t index) -> ChildPair {
         const uint32_t q = lds_inner + index * 64u;
         uint4 a, b, c; uint2 r;
-        if (DRT_POOL_GLOBAL_SCENE) {
+        if (HBM) {
             const uint4 *g = reinterpret_cast<const uint4 *>(sc.inner) + (size_t)index * 4;
             a = g[0]; b = g[1]; c = g[2]; r = *reinterpret_cast<const uint2 *>(g + 3);
         } else { a = ld4(q); b = ld4(q + 16); c = ld4(q + 32); r = ld2(q + 48); }
@@ -233,6 +254,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         return p;
     };
     auto fetch_face_normal = [&](int prim) -> f3 {
+        if (HBM) return ld3(sc.tri_hot[prim].fn);
         const uint32_t q = lds_hot + __umul24((uint32_t)prim, 48u) + 36u;
         return mk3(u2f(ld1(q)), u2f(ld1(q + 4)), u2f(ld1(q + 8)));
     };
@@ -257,29 +279,47 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         TexDev t; t.width = (int32_t)a.x; t.height = (int32_t)a.y; t.comps = (int32_t)a.z; t.offset = a.w;
         return t;
     };
-    // leaf -> (first triangle, end) packed with the stack height, and the T queue of its size class
-    auto leaf_state = [&](uint32_t leaf_ref, int sp, uint32_t &packed) -> int {          // leaf_ref = count << 12 | first triangle
-        if (DRT_POOL_GLOBAL_SCENE) { const LeafRange lr = sc.leaves[leaf_ref]; leaf_ref = ((uint32_t)lr.count << 12) | (uint32_t)lr.start; }
-        const uint32_t cur = leaf_ref & 0xFFFu, count = leaf_ref >> 12;
-        packed = cur | ((cur + count) << 12) | ((uint32_t)sp << 24);
+    // leaf -> its triangles [cur, end) and the T queue of its size class.  leaf_ref: count << 12 | first triangle in the lds-scene
+    // build (the staged records carry it), the leaf's index in the hbm-scene build
+    auto leaf_state = [&](uint32_t leaf_ref, uint32_t &cur, uint32_t &end) -> int {
+        uint32_t count;
+        if (HBM) { const LeafRange lr = sc.leaves[leaf_ref]; cur = (uint32_t)lr.start; count = (uint32_t)lr.count; }
+        else { cur = leaf_ref & 0xFFFu; count = leaf_ref >> 12; }
+        end = cur + count;
         const uint32_t steps = (count + 1u) >> 1;
         return QT0 + (steps <= pp.t_class[0] ? 0 : (steps <= pp.t_class[1] ? 1 : (steps <= pp.t_class[2] ? 2 : 3)));
     };
     // traversal over: a path with a hit is shaded (B), one without ends on the sky (E)
     // (a shadow traversal: on to S, the second half of the shading)
     auto after_traversal = [&](float hit_t, bool shadow) -> int { return shadow ? QS : (hit_t < FLT_MAX ? QB : QE); };
+    // Stack entries {node reference, slab distance}, [level][path]: 8 bytes in the lds-scene build; the hbm-scene build, whose deep trees
+    // make the stacks most of a path's LDS, keeps the distances in one array and 16-bit references (bit 15 = leaf) in another:
+    // 6 bytes, a quarter more paths per CU (path_pool_supports: fewer than 32768 interior nodes and leaves)
+    const uint32_t stack_refs = stack + pp.stack_entries * P * 4u;
+    auto stack_load = [&](int level, uint32_t id) -> uint2 {
+        const uint32_t at = (uint32_t)level * P + id;
+        if (!HBM) return ld2(stack + at * 8u);
+        const uint32_t r16 = ld_u16(stack_refs + at * 2u);
+        return make_uint2((r16 & 0x8000u) ? (kLeafBit | (r16 & 0x7FFFu)) : r16, ld1(stack + at * 4u));
+    };
+    auto stack_store = [&](int level, uint32_t id, uint2 e) {
+        const uint32_t at = (uint32_t)level * P + id;
+        if (!HBM) { st2(stack + at * 8u, e); return; }
+        st_u16(stack_refs + at * 2u, (e.x & kLeafBit) ? (0x8000u | (e.x & 0x7FFFu)) : e.x);
+        st1(stack + at * 4u, e.y);
+    };
     // One visit of BVHTraversal.cuh:33-72.  The entry to visit is `top` when have_top is set (an entry that would have been pushed
     // and popped again at once: it never goes through LDS), else the stack's top.  Returns the T queue when the path now stands on
-    // a leaf (packed = its triangle range + stack height), else -1 (entry culled, or an interior node: its far child went on
+    // a leaf ([cur, end) = its triangles), else -1 (entry culled, or an interior node: its far child went on
     // the stack, its near child -- the next visit -- into `top`).  (ray.dir is not used: the slab test needs origin and 1/dir.)
-    auto pop_step = [&](const Ray &ray, float hit_t, int &sp, uint32_t id, uint32_t &packed, uint2 &top, bool &have_top) -> int {
+    auto pop_step = [&](const Ray &ray, float hit_t, int &sp, uint32_t id, uint32_t &cur, uint32_t &end, uint2 &top, bool &have_top) -> int {
         uint2 e = top;
-        if (!have_top) { --sp; e = ld2(stack + ((uint32_t)sp * P + id) * 8u); }
+        if (!have_top) { --sp; e = stack_load(sp, id); }
         have_top = false;
         int dest = -1;
         // :41 (without a hit, hit_t = FLT_MAX > dist); :38 was applied when the root was pushed
         if (!(hit_t < u2f(e.y))) {
-            if (e.x & kLeafBit) dest = leaf_state(e.x & ~kLeafBit, sp, packed);
+            if (e.x & kLeafBit) dest = leaf_state(e.x & ~kLeafBit, cur, end);
             else {
                 const ChildPair c = fetch_children(e.x);
                 const float d1 = slab_entry_or_inf(c.min1, c.max1, ray);
@@ -287,11 +327,11 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 const bool first_is_1 = d1 > d2;          // farther child first; child 2 first on ties (:63-70)
                 const uint32_t ra = first_is_1 ? c.ref1 : c.ref2, rb = first_is_1 ? c.ref2 : c.ref1;
                 const float da = first_is_1 ? d1 : d2, db = first_is_1 ? d2 : d1;
-                if (da < hit_t) { st2(stack + ((uint32_t)sp * P + id) * 8u, make_uint2(ra, f2u(da))); ++sp; }
+                if (da < hit_t) { stack_store(sp, id, make_uint2(ra, f2u(da))); ++sp; }
                 if (db < hit_t) {
                     // the near child is this path's next visit and passes :41 (nothing changes hit_t in between): a leaf goes
                     // straight to T, an interior node stays in registers
-                    if (rb & kLeafBit) dest = leaf_state(rb & ~kLeafBit, sp, packed);
+                    if (rb & kLeafBit) dest = leaf_state(rb & ~kLeafBit, cur, end);
                     else { top = make_uint2(rb, f2u(db)); have_top = true; }
                 }
             }
@@ -300,7 +340,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     };
     // a path leaves a batch with an entry still in registers: it goes on the stack after all
     auto spill_top = [&](int &sp, uint32_t id, const uint2 &top, bool &have_top) {
-        if (have_top) { st2(stack + ((uint32_t)sp * P + id) * 8u, top); ++sp; have_top = false; }
+        if (have_top) { stack_store(sp, id, top); ++sp; have_top = false; }
     };
     // Push every lane's path id (dest >= 0) to its destination queue: one atomic add per destination present in the wave
     // (issued together by the first lane of each group), then the ids go to consecutive ring positions.
@@ -332,7 +372,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     const f3 root_min = ld3(sc.root_min), root_max = ld3(sc.root_max);
     // TraceRay.cu:15-20 + BVHTraversal.cuh:22-26,38: the root goes on the stack with its slab distance when -1 < d < FLT_MAX
     uint32_t root_ref = sc.root_ref;                      // (a one-leaf scene: the same self-describing form as the staged records)
-    if (!DRT_POOL_GLOBAL_SCENE && root_ref != kNoNode && (root_ref & kLeafBit)) { const LeafRange lr = sc.leaves[root_ref & ~kLeafBit]; root_ref = kLeafBit | ((uint32_t)lr.count << 12) | (uint32_t)lr.start; }
+    if (!HBM && root_ref != kNoNode && (root_ref & kLeafBit)) { const LeafRange lr = sc.leaves[root_ref & ~kLeafBit]; root_ref = kLeafBit | ((uint32_t)lr.count << 12) | (uint32_t)lr.start; }
     auto begin_closest = [&](const Ray &ray, uint2 &top) -> bool {
         if (sc.root_ref == kNoNode) return false;
         const float d = slab_intersect(root_min, root_max, ray);
@@ -344,24 +384,30 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     // stored.  Returns the queue the path goes to.
     auto launch_with = [&](uint32_t id, const Ray &ray, uint32_t w_word, uint2 top, bool have_top, bool shadow) -> int {
         int sp = 0;
-        uint32_t packed = 0;
+        uint32_t cur = 0, end = 0;
         int dest = -1;
-        if (have_top) dest = pop_step(ray, FLT_MAX, sp, id, packed, top, have_top);     // the root's visit
+        if (have_top) dest = pop_step(ray, FLT_MAX, sp, id, cur, end, top, have_top);   // the root's visit
         if (dest < 0) {
             spill_top(sp, id, top, have_top);
-            packed = (uint32_t)sp << 24;
+            cur = end = 0;
             dest = sp > 0 ? QN : after_traversal(FLT_MAX, shadow);                       // nothing to traverse: sky (E) / not occluded (S)
         }
         // hit distance FLT_MAX: for a shadow ray it stays there, so that N's culls (:41, :63-70) never apply -- RayTest has none
         st4(qA + id * 16u, make_uint4(f2u(ray.orig.x), f2u(ray.orig.y), f2u(ray.orig.z), f2u(FLT_MAX)));
-        st4(qB + id * 16u, make_uint4(f2u(ray.dir.x), f2u(ray.dir.y), f2u(ray.dir.z), packed));
-        st1(qW + id * 4u, w_word);
+        if (HBM) {
+            st4(qB + id * 16u, make_uint4(f2u(ray.dir.x), f2u(ray.dir.y), f2u(ray.dir.z), cur));
+            st1(meta_at(id), w_word | ((uint32_t)sp << 16));
+            st1(meta_at(id) + 8u, end);
+        } else {
+            st4(qB + id * 16u, make_uint4(f2u(ray.dir.x), f2u(ray.dir.y), f2u(ray.dir.z), cur | (end << 12) | ((uint32_t)sp << 24)));
+            st1(meta_at(id), w_word);
+        }
         return dest;
     };
     auto launch_ray = [&](uint32_t id, const Ray &ray, uint32_t bounce, bool trace) -> int {
         uint2 top = make_uint2(0u, 0u);
         const bool have_top = trace && begin_closest(ray, top);
-        return launch_with(id, ray, kNoPrim | (bounce << 12) | kHasSample, top, have_top, false);
+        return launch_with(id, ray, make_meta(kNoPrim, bounce, kHasSample), top, have_top, false);
     };
     // RayTest (BVHTraversal.cuh:76-134): the root is visited unless its slab test says "behind" (:95-103), no distance culls
     auto launch_shadow = [&](uint32_t id, const Ray &ray, uint32_t w_word) -> int {
@@ -481,7 +527,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                     if (store_throughput) aux[id] = make_uint4(f2u(dir_thr.x), f2u(dir_thr.y), f2u(dir_thr.z), dir_seed);
                     st4(qA + id * 16u, make_uint4(f2u(dir_origin.x), f2u(dir_origin.y), f2u(dir_origin.z), dir_seed));
                     st4(qB + id * 16u, make_uint4(f2u(dir_normal.x), f2u(dir_normal.y), f2u(dir_normal.z), dir_tries));
-                    st1(qW + id * 4u, kNoPrim | (dir_bounce << 12) | kHasSample);
+                    st1(meta_at(id), make_meta(kNoPrim, dir_bounce, kHasSample));
                     dest = QR;
                 }
             }
@@ -492,14 +538,15 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             Ray ray = make_ray(mk3(0, 0, 0), mk3(0, 0, 1));
             float hit_t = FLT_MAX;
             int sp = 0;
-            uint32_t packed = 0;
+            uint32_t cur = 0, end = 0, meta = 0;
             bool shadow = false;
             if (active) {
                 const uint4 A = ld4(qA + id * 16u), B = ld4(qB + id * 16u);
-                sp = (int)(B.w >> 24);
+                if (HBM || SUN) meta = ld1(meta_at(id));
+                sp = HBM ? (int)((meta >> 16) & 0xFFu) : (int)(B.w >> 24);
                 hit_t = u2f(A.w);
                 ray = make_ray(mk3(u2f(A.x), u2f(A.y), u2f(A.z)), mk3(u2f(B.x), u2f(B.y), u2f(B.z)));     // 1/dir again (Ray.cuh:7-9): 12 bytes of LDS per path saved
-                if (SUN) shadow = (ld1(qW + id * 4u) & kShadow) != 0;
+                if (SUN) shadow = (meta & kShadow) != 0;
             }
             uint2 top = make_uint2(0u, 0u);
             bool have_top = false;
@@ -508,28 +555,51 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 const unsigned long long m_go = pp_ballot(go);
                 // lanes that are done wait for the others only while enough of them are still popping
                 if (m_go == 0 || it >= pp.n_loop || (it > 0 && (uint32_t)__popcll(m_go) < pp.n_min_lanes)) break;
-                if (go) dest = pop_step(ray, hit_t, sp, id, packed, top, have_top);
+                if (go) dest = pop_step(ray, hit_t, sp, id, cur, end, top, have_top);
             }
             if (active) {
-                if (dest < 0) { spill_top(sp, id, top, have_top); packed = (uint32_t)sp << 24; dest = sp > 0 ? QN : after_traversal(hit_t, shadow); }
-                st1(qB + id * 16u + 12u, packed);
+                if (dest < 0) { spill_top(sp, id, top, have_top); cur = end = 0; dest = sp > 0 ? QN : after_traversal(hit_t, shadow); }
+                store_trav(id, sp, cur, end, meta);
             }
         } else if (q >= QT0 && q < QB) {
             // ============ T: the triangles of one leaf, two per step (Intersection.cu:4-36, BVHTraversal.cuh:46-57) ============
             Ray ray = make_ray(mk3(0, 0, 0), mk3(0, 0, 1));
             float hit_t = FLT_MAX;
-            uint32_t hit_prim = kNoPrim;
+            uint32_t hit_prim = 0, meta = 0;
             int cur = 0, end = 0, sp = 0;
             bool shadow = false, occluded = false;
             if (active) {
                 const uint4 A = ld4(qA + id * 16u), B = ld4(qB + id * 16u);
                 ray.orig = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); hit_t = u2f(A.w);
                 ray.dir = mk3(u2f(B.x), u2f(B.y), u2f(B.z));
-                cur = (int)(B.w & 0xFFFu); end = (int)((B.w >> 12) & 0xFFFu); sp = (int)(B.w >> 24);
-                if (SUN) shadow = (ld1(qW + id * 4u) & kShadow) != 0;
+                if (HBM || SUN) meta = ld1(meta_at(id));
+                if (HBM) { cur = (int)B.w; end = (int)ld1(meta_at(id) + 8u); sp = (int)((meta >> 16) & 0xFFu); }
+                else { cur = (int)(B.w & 0xFFFu); end = (int)((B.w >> 12) & 0xFFFu); sp = (int)(B.w >> 24); }
+                if (SUN) shadow = (meta & kShadow) != 0;
             }
             const float hit_t_in = hit_t;
-            while (pp_ballot(cur < end) != 0) {
+            // hbm-scene: four triangles per step -- four loads in flight per lane instead of two (the step waits for memory, not for
+            // the arithmetic); tested and applied in the leaf's order
+            while (HBM && pp_ballot(cur < end) != 0) {
+                if (cur < end) {
+                    constexpr int kWide = 4;
+                    int idx[kWide];
+                    TriTest tri[kWide];
+#pragma unroll
+                    for (int k = 0; k < kWide; k++) { idx[k] = min(cur + k, end - 1); tri[k] = fetch_tri(idx[k]); }
+                    const int first = cur;
+                    cur = min(cur + kWide, end);
+#pragma unroll
+                    for (int k = 0; k < kWide; k++) {
+                        float t, u, v;
+                        const bool h = tri_intersect_flat(ray, tri[k].v0, tri[k].e1, tri[k].e2, t, u, v) & (first + k < end);
+                        if (SUN && shadow) {
+                            if (h && (!ALPHA || any_hit(sc, idx[k], mk3(1.0f - u - v, u, v)))) { occluded = true; cur = end; sp = 0; }
+                        } else if (h && t < hit_t && (!ALPHA || any_hit(sc, idx[k], mk3(1.0f - u - v, u, v)))) { hit_t = t; hit_prim = (uint32_t)idx[k]; }
+                    }
+                }
+            }
+            while (!HBM && pp_ballot(cur < end) != 0) {
                 if (cur < end) {
                     const int i = cur;
                     const bool two = i + 1 < end;
@@ -551,22 +621,23 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 }
             }
             if (active) {
-                if (SUN && occluded) st1(qW + id * 4u, ld1(qW + id * 4u) | kOccluded);
+                if (SUN && occluded) { meta |= kOccluded; if (!HBM) st1(meta_at(id), meta); }      // (hbm-scene: store_trav writes meta)
                 if (hit_t < hit_t_in) {
                     st1(qA + id * 16u + 12u, f2u(hit_t));
-                    st1(qW + id * 4u, (ld1(qW + id * 4u) & ~0xFFFu) | hit_prim);
+                    if (HBM) st1(meta_at(id) + 4u, hit_prim);
+                    else st1(meta_at(id), (ld1(meta_at(id)) & ~0xFFFu) | hit_prim);
                 }
                 // What the next pops would do while the top of the stack is culled (:41) or a leaf: done here, the path goes
                 // straight to its next leaf; an interior node is left to N.
-                uint32_t packed = 0;
+                uint32_t next_cur = 0, next_end = 0;
                 while (sp > 0) {
-                    const uint2 e = ld2(stack + ((uint32_t)(sp - 1) * P + id) * 8u);
+                    const uint2 e = stack_load(sp - 1, id);
                     if (hit_t < u2f(e.y)) { --sp; continue; }
-                    if (e.x & kLeafBit) { --sp; dest = leaf_state(e.x & ~kLeafBit, sp, packed); }
+                    if (e.x & kLeafBit) { --sp; dest = leaf_state(e.x & ~kLeafBit, next_cur, next_end); }
                     break;
                 }
-                if (dest < 0) { packed = (uint32_t)sp << 24; dest = sp > 0 ? QN : after_traversal(hit_t, shadow); }
-                st1(qB + id * 16u + 12u, packed);
+                if (dest < 0) dest = sp > 0 ? QN : after_traversal(hit_t, shadow);
+                store_trav(id, sp, next_cur, next_end, meta);
             }
         } else if (q == QR) {
             // ============ R: more candidates for directions B could not settle (Random.cu:50-58), then the launch ============
@@ -575,7 +646,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 need_dir = true;
                 dir_origin = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); dir_seed = A.w;
                 dir_normal = mk3(u2f(B.x), u2f(B.y), u2f(B.z)); dir_tries = B.w;
-                dir_bounce = (ld1(qW + id * 4u) >> 12) & 0xFFFFu;
+                dir_bounce = bounce_of(ld1(meta_at(id)));
             }
             draw_and_launch(false);
         } else if (q == QB) {
@@ -583,11 +654,11 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             if (active) {
                 const uint4 E = aux[id];                                                   // {throughput, seed}
                 const uint4 A = ld4(qA + id * 16u), B = ld4(qB + id * 16u);
-                const uint32_t W = ld1(qW + id * 4u);
+                const uint32_t W = ld1(meta_at(id));
                 Ray ray; ray.orig = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); ray.dir = mk3(u2f(B.x), u2f(B.y), u2f(B.z)); ray.inv_dir = ray.dir;
                 const float hit_t = u2f(A.w);
-                const int hit_prim = (int)(W & 0xFFFu);
-                uint32_t bounce = (W >> 12) & 0xFFFFu;
+                const int hit_prim = (int)prim_of(id, W);
+                uint32_t bounce = bounce_of(W);
                 // the barycentrics of the hit: the winning triangle's test once more (same inputs, same bits as in T)
                 float hit_u, hit_v, t_again;
                 const TriTest tri = fetch_tri(hit_prim);
@@ -607,7 +678,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                     // again from the triangle and the side bit; the rest of this iteration is S's, after the shadow traversal
                     const Ray sun_ray = make_ray(origin, ld3(fp.sunpos) + random_unit_vec3(seed) * 1.5f);
                     aux[id] = make_uint4(f2u(throughput.x), f2u(throughput.y), f2u(throughput.z), seed);
-                    dest = launch_shadow(id, sun_ray, (uint32_t)hit_prim | (bounce << 12) | kHasSample | kShadow | (front_face ? 0u : kBackFace));
+                    dest = launch_shadow(id, sun_ray, make_meta((uint32_t)hit_prim, bounce, kHasSample | kShadow | (front_face ? 0u : kBackFace)));
                 } else {
                     ++bounce;
                     if ((int)bounce <= fp.bounce_limit) {                                  // :88 loop condition
@@ -625,20 +696,20 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             if (active) {
                 const uint4 E = aux[id];
                 const uint4 A = ld4(qA + id * 16u);
-                const uint32_t W = ld1(qW + id * 4u);
+                const uint32_t W = ld1(meta_at(id));
                 if (!(W & kOccluded)) {
                     float4 *const lp = aux_light + id;
                     const f3 light = mk3(lp->x, lp->y, lp->z) + ld3(fp.suncol) * mk3(u2f(E.x), u2f(E.y), u2f(E.z));     // :126-127
                     *lp = make_float4(light.x, light.y, light.z, 0.0f);
                 }
-                const uint32_t bounce = ((W >> 12) & 0xFFFFu) + 1u;
+                const uint32_t bounce = bounce_of(W) + 1u;
                 if ((int)bounce <= fp.bounce_limit) {                                      // :88 loop condition
-                    const f3 fn = fetch_face_normal((int)(W & 0xFFFu));
+                    const f3 fn = fetch_face_normal((int)prim_of(id, W));
                     need_dir = true; dir_origin = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); dir_normal = (W & kBackFace) ? (-1.f * fn) : fn;
                     dir_seed = E.w; dir_bounce = bounce; dir_tries = 0;
                 } else {
                     st1(qA + id * 16u + 12u, 0u);        // the path ends without reaching the sky
-                    st1(qW + id * 4u, kNoPrim | kHasSample);
+                    st1(meta_at(id), make_meta(kNoPrim, 0u, kHasSample));
                     dest = QE;
                 }
             }
@@ -646,7 +717,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         } else {
             // ============ E: finish the path, store its sample; deal a new sample, primary ray (RayGen.cuh:63-108,165-171) ============
             if (active) {
-                if (ld1(qW + id * 4u) & kHasSample) {
+                if (ld1(meta_at(id)) & kHasSample) {
                     const uint4 E = aux[id];
                     const uint32_t slot = aux_slot[id];
                     const uint4 B = ld4(qB + id * 16u);
@@ -701,7 +772,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                         if (SUN) aux_light[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         if (fp.bounce_limit < 0) st1(qA + id * 16u + 12u, 0u);            // RayGen.cuh:88: the loop body never runs, the sample is black
                     } else {
-                        st1(qW + id * 4u, kNoPrim);         // a sample id outside the image (partial tile): the slot asks again
+                        st1(meta_at(id), HBM ? 0u : kNoPrim);       // a sample id outside the image (partial tile): the slot asks again
                         dest = QE;
                     }
                 }
@@ -752,21 +823,26 @@ void path_pool_leaf_classes(const std::vector<LeafRange> &leaves, uint32_t out[3
             }
 }
 
-bool path_pool_supports(const SceneView &sc, const FrameParams &fp, int bvh_depth, bool scene_has_alpha, size_t scene_lds_bytes) {
-    (void)scene_has_alpha;
+// Does the pool apply, and in which build: *hbm_scene = the traversal data does not fit LDS next to a pool and is read from global memory.
+bool path_pool_supports(const SceneView &sc, const FrameParams &fp, int bvh_depth, size_t scene_lds_bytes, bool *hbm_scene) {
     if (fp.render_mode != 0) return false;                                                // no debug views (wave_queue's general build)
-    static const size_t scene_limit = std::getenv("DRT_POOL_SCENE_KB") ? (size_t)std::atoi(std::getenv("DRT_POOL_SCENE_KB")) * 1024 : kLdsSceneBytes;
-    if (scene_lds_bytes > scene_limit || sc.n_tris >= 4095u || bvh_depth > 200) return false;
-    if (fp.bounce_limit > 60000) return false;                                            // the bounce index is kept in 16 bits
+    if (fp.bounce_limit > 60000 || bvh_depth > 200) return false;                         // bounce index in 16 bits, stack height in 8
     if (sc.root_ref == kNoNode) return false;
-    // a pool of at least 256 paths has to fit the CU's LDS next to the scene copy (a very deep tree's stacks may not leave room)
+    static const size_t scene_limit = std::getenv("DRT_POOL_SCENE_KB") ? (size_t)std::atoi(std::getenv("DRT_POOL_SCENE_KB")) * 1024 : kLdsSceneBytes;
+    static const bool hbm_allowed = !(std::getenv("DRT_POOL_HBM") && std::atoi(std::getenv("DRT_POOL_HBM")) == 0);
     const uint32_t stack_entries = (uint32_t)std::max(bvh_depth - 1, 1);
-    if (pool_layout(512u, 512u, stack_entries, pool_scene_bytes(sc), 0u, (uint32_t)kNQ).total > 160u * 1024u &&
-        (scene_lds_bytes > kLdsSceneBytes || pool_layout(256u, 256u, stack_entries, pool_scene_bytes(sc), 0u, (uint32_t)kNQ).total > 160u * 1024u)) return false;
-    return true;
+    // lds-scene build: 12-bit triangle indices, and a pool of at least 256 paths has to fit the CU's LDS next to the scene copy
+    // (a very deep tree's stacks may not leave room)
+    bool in_lds = scene_lds_bytes <= scene_limit && sc.n_tris < 4095u;
+    if (in_lds && pool_layout(512u, 512u, stack_entries, pool_scene_bytes(sc), 0u, (uint32_t)kNQ).total > 160u * 1024u &&
+        (scene_lds_bytes > kLdsSceneBytes || pool_layout(256u, 256u, stack_entries, pool_scene_bytes(sc), 0u, (uint32_t)kNQ).total > 160u * 1024u)) in_lds = false;
+    if (hbm_scene) *hbm_scene = !in_lds;
+    if (in_lds) return true;
+    return hbm_allowed && sc.n_inner < 32768u && sc.n_leaves < 32768u &&               // 16-bit node references on the stacks
+           pool_layout(256u, 256u, stack_entries, 0u, 0u, (uint32_t)kNQ, 16u, 6u).total <= 160u * 1024u;
 }
 
-hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_depth, bool scene_has_alpha, const uint32_t t_class[3], const PoolTuning &tune,
+hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_depth, bool scene_has_alpha, bool hbm_scene, const uint32_t t_class[3], const PoolTuning &tune,
                             PoolScratch &scratch, unsigned int *sample_counter, void *samples, unsigned int *status, int num_cus,
                             hipStream_t stream, const char **kernel_name, int *launch_shape) {
     if (fp.width == 0 || fp.local_rows == 0 || fp.n_frames == 0) return hipSuccess;
@@ -782,7 +858,8 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     // mod P by multiplication -- were tried too: room's pool grows from 1216 to 1344 paths, and the extra arithmetic in every claim
     // and push costs the 3 % that buys.)
     const uint32_t stack_entries = (uint32_t)std::max(bvh_depth - 1, 1);
-    const uint32_t scene_bytes = pool_scene_bytes(sc);
+    const uint32_t scene_bytes = hbm_scene ? 0u : pool_scene_bytes(sc);
+    const uint32_t word_bytes = hbm_scene ? 16u : 4u, stack_entry_bytes = hbm_scene ? 6u : 8u;
     // the shading records go to LDS too when they are small (cornell: 1.2 KB): B's load chain triangle -> material ->
     // texture header then runs through LDS instead of three dependent HBM / L2 round trips
     const uint32_t cold_bytes = pool_cold_bytes(sc) <= (tune.cold_lds_kb >= 0 ? (uint32_t)tune.cold_lds_kb * 1024u : 4096u) ? pool_cold_bytes(sc) : 0u;
@@ -792,7 +869,7 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     auto lds_for = [&](uint32_t paths, uint32_t &cap) {
         cap = 64;
         while (cap < paths) cap *= 2;
-        return pool_layout(paths, cap, stack_entries, scene_bytes, cold_bytes, n_rings).total;
+        return pool_layout(paths, cap, stack_entries, scene_bytes, cold_bytes, n_rings, word_bytes, stack_entry_bytes).total;
     };
     uint32_t P = 0, ring_cap = 64;
     int groups = 1;
@@ -802,7 +879,8 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
         (void)lds_for(P, ring_cap);
     } else {
         uint32_t best_total = 0;
-        for (int g = 1; g <= 3; g++)
+        // (hbm-scene: one pool per CU -- what counts there is resident waves AND spare paths, and one big pool has both)
+        for (int g = 1; g <= (hbm_scene ? 1 : 3); g++)
             for (uint32_t paths = 4032u; paths >= 256u; paths -= 64u) {
                 uint32_t cap;
                 if (lds_for(paths, cap) * (uint32_t)g > 160u * 1024u) continue;
@@ -812,17 +890,22 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
         if (P == 0) return hipErrorInvalidValue;
         (void)lds_for(P, ring_cap);
     }
-    const PoolLayout lay = pool_layout(P, ring_cap, stack_entries, scene_bytes, cold_bytes, n_rings);
+    const PoolLayout lay = pool_layout(P, ring_cap, stack_entries, scene_bytes, cold_bytes, n_rings, word_bytes, stack_entry_bytes);
     if (lay.total > 160u * 1024u) return hipErrorInvalidValue;
+    const int flags = (tune.stats ? 1 : 0) | (fp.enable_sunlight ? 2 : 0) | (scene_has_alpha ? 4 : 0) | (hbm_scene ? 8 : 0);
     int threads;
     if (env_threads > 0) threads = std::max(64, std::min(env_threads, kMaxPoolThreads) / 64 * 64);
     else threads = std::max(256, std::min<int>({ kMaxPoolThreads, (int)P / 64 * 64, 1536 / groups / 64 * 64 }));
-    const int flags = (tune.stats ? 1 : 0) | (fp.enable_sunlight ? 2 : 0) | (scene_has_alpha ? 4 : 0);
+    // hbm-scene: every step waits for L2, so all the waves a workgroup can have (even a few more lanes than paths: measured on cs16_dust)
+    if (hbm_scene && env_threads <= 0) threads = kMaxPoolThreads;
     typedef void (*PoolKernel)(const SceneView, const FrameParams, const PoolParams, unsigned int *, float4 *);
-    static const PoolKernel kernels[8] = { path_pool_kernel<0>, path_pool_kernel<1>, path_pool_kernel<2>, path_pool_kernel<3>,
-                                           path_pool_kernel<4>, path_pool_kernel<5>, path_pool_kernel<6>, path_pool_kernel<7> };
-    static const char *const names[4] = { "path_pool<lean,lds-scene>", "path_pool<lean+sun,lds-scene>", "path_pool<lean+alpha,lds-scene>",
-                                          "path_pool<lean+alpha+sun,lds-scene>" };
+    static const PoolKernel kernels[16] = { path_pool_kernel<0>, path_pool_kernel<1>, path_pool_kernel<2>, path_pool_kernel<3>,
+                                            path_pool_kernel<4>, path_pool_kernel<5>, path_pool_kernel<6>, path_pool_kernel<7>,
+                                            path_pool_kernel<8>, path_pool_kernel<9>, path_pool_kernel<10>, path_pool_kernel<11>,
+                                            path_pool_kernel<12>, path_pool_kernel<13>, path_pool_kernel<14>, path_pool_kernel<15> };
+    static const char *const names[8] = { "path_pool<lean,lds-scene>", "path_pool<lean+sun,lds-scene>", "path_pool<lean+alpha,lds-scene>",
+                                          "path_pool<lean+alpha+sun,lds-scene>", "path_pool<lean,hbm-scene>", "path_pool<lean+sun,hbm-scene>",
+                                          "path_pool<lean+alpha,hbm-scene>", "path_pool<lean+alpha+sun,hbm-scene>" };
     const PoolKernel kernel = kernels[flags];
     if (lay.total > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total);
@@ -843,9 +926,12 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     // launches in flight (drt_renderer_set_frames_in_flight) each gets its share of the workgroup slots, so that they run side
     // by side and the ramp-up and drain of one overlap the steady state of the others instead of queueing behind a full grid.
     uint64_t want = std::min<uint64_t>((uint64_t)num_cus * per_cu, std::max<uint64_t>(1, (n_chunks * 64ull + P - 1) / P));
-    // (only launches short enough for ramp-up and drain to matter: a launch that refills its pools a hundred times runs best
-    // on the whole chip -- room 4K / 64 spp, two frames in flight: 998 ms per step with half a grid each, 757 with full grids)
-    if (fp.frames_in_flight > 1 && tune.share_grid && n_chunks * 64ull < 64ull * (uint64_t)num_cus * per_cu * P)
+    // (only launches short enough for ramp-up and drain to matter -- dense_monkey 16 spp, 145 refills: 7.3 -> 8.8 Gsamples/s; a launch
+    // that refills its pools two hundred times runs best on the whole chip: room 4K / 64 spp with three frames in flight, 1029 ms
+    // per step on a third of the grid each against 694 with full grids)
+    // (DRT_POOL_SHARE_GRID = the number of pool refills below which a launch shares; 1 = the default of 160, 0 = never)
+    const uint64_t share_refills = tune.share_grid == 1 ? 160ull : (uint64_t)std::max(0, tune.share_grid);
+    if (fp.frames_in_flight > 1 && share_refills > 0 && n_chunks * 64ull < share_refills * (uint64_t)num_cus * per_cu * P)
         want = std::min<uint64_t>(want, std::max<uint64_t>(1, ((uint64_t)num_cus * per_cu + fp.frames_in_flight - 1) / (uint64_t)fp.frames_in_flight));
     // the part of the path state that lives in HBM: 36 bytes per pool slot of every workgroup (16 of them used by sunlight only)
     const size_t slots = (size_t)num_cus * per_cu * P;

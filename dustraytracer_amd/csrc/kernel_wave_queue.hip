@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <functional>
 #include <cstdlib>
 #include <vector>
 
@@ -809,26 +810,8 @@ hipError_t launch_one(const SceneView &sc, const FrameParams &fp, unsigned int *
     for (int k = 0; k < 3; k++) camera_inside = camera_inside && fp.cam_pos[k] >= sc.root_min[k] && fp.cam_pos[k] <= sc.root_max[k];
     // one plan per (kernel, scene shape, view class)
     const uint64_t key = ((((uint64_t)scene_lds_bytes * 131u + stack_entries) * 131u + sc.n_tris) * 16u + (uint64_t)MODE * 2u + (LDS_SCENE ? 1u : 0u)) * 2u + (camera_inside ? 1u : 0u);
-    WqPlan *plan = nullptr;
-    for (WqPlan &p : cache.plans) if (p.key == key) plan = &p;
-    if (!plan) {
-        if (cache.plans.size() >= 32) cache.plans.erase(cache.plans.begin());
-        cache.plans.emplace_back();
-        plan = &cache.plans.back();
-        plan->key = key;
-        plan->cands = wave_queue_candidates<MODE, LDS_SCENE>(sc, stack_entries, scene_lds_bytes, camera_inside);
-        plan->ns_per_sample.assign(plan->cands.size(), -1.0);
-        plan->trials.assign(plan->cands.size(), 0);
-        plan->chosen = plan->cands.size() == 1 ? 0 : -1;
-    }
-    int use = plan->chosen;
-    if (use < 0) {                      // still measuring: the candidate with the fewest trials so far (the batch keeps one candidate)
-        if (cache.batch_key == key && cache.batch_cand >= 0) use = cache.batch_cand;
-        else { use = 0; for (size_t i = 1; i < plan->cands.size(); i++) if (plan->trials[i] < plan->trials[(size_t)use]) use = (int)i; }
-    }
-    cache.batch_key = key; cache.batch_cand = use;
-    cache.batch_samples += (double)fp.width * fp.local_rows * fp.n_frames;
-    const WqVariant v = plan->cands[(size_t)use];
+    const WqVariant v = measured_choice(cache, key, (double)fp.width * fp.local_rows * fp.n_frames,
+                                        [&] { return wave_queue_candidates<MODE, LDS_SCENE>(sc, stack_entries, scene_lds_bytes, camera_inside); });
     const size_t lds_bytes = (size_t)stack_entries * v.threads * v.entry_bytes + scene_lds_bytes;
     if (launch_shape) { launch_shape[0] = (int)stack_entries; launch_shape[1] = v.per_cu; launch_shape[2] = (int)(lds_bytes / 1024); launch_shape[3] = v.threads + (v.entry_bytes == 6 ? 1 : 0) + (v.tris == 3 ? 2 : 0); }
     if (v.tris == 3)
@@ -858,6 +841,32 @@ hipError_t launch_mode(const SceneView &sc, const FrameParams &fp, int mode, boo
 }
 
 }  // namespace
+
+// The plan of `key` (made from `candidates()` the first time) and the candidate this launch uses: the chosen one, or -- while the
+// plan is still measuring -- the one with the fewest trials so far (a batch keeps one candidate; wave_queue_report feeds the time back).
+WqVariant measured_choice(WaveQueueCache &cache, uint64_t key, double samples, const std::function<std::vector<WqVariant>()> &candidates) {
+    WqPlan *plan = nullptr;
+    for (WqPlan &p : cache.plans) if (p.key == key) plan = &p;
+    if (!plan) {
+        if (cache.plans.size() >= 32) cache.plans.erase(cache.plans.begin());
+        cache.plans.emplace_back();
+        plan = &cache.plans.back();
+        plan->key = key;
+        plan->cands = candidates();
+        plan->ns_per_sample.assign(plan->cands.size(), -1.0);
+        plan->trials.assign(plan->cands.size(), 0);
+        plan->chosen = plan->cands.size() == 1 ? 0 : -1;
+    }
+    int use = plan->chosen;
+    if (use < 0) {
+        if (cache.batch_key == key && cache.batch_cand >= 0) use = cache.batch_cand;
+        else { use = 0; for (size_t i = 1; i < plan->cands.size(); i++) if (plan->trials[i] < plan->trials[(size_t)use]) use = (int)i; }
+    }
+    cache.batch_key = key; cache.batch_cand = use;
+    cache.batch_samples += samples;
+    return plan->cands[(size_t)use];
+}
+
 
 hipError_t launch_check_rcp(int which, uint32_t first_bits, unsigned long long count, unsigned long long *d_out2, hipStream_t stream) {
     hipLaunchKernelGGL(check_rcp_kernel, dim3(4096), dim3(256), 0, stream, which, first_bits, count, d_out2, d_out2 + 1);

@@ -3,6 +3,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <functional>
+#include <vector>
+
 #include "device_scene.hpp"
 
 namespace drt {
@@ -17,6 +20,7 @@ struct WqVariant { int threads, entry_bytes, tris, per_cu; };
 struct WqPlan { uint64_t key = 0; std::vector<WqVariant> cands; std::vector<double> ns_per_sample; std::vector<int> trials; int chosen = -1; };
 struct WaveQueueCache { std::vector<WqPlan> plans; uint64_t batch_key = 0; int batch_cand = -1; double batch_samples = 0; };
 void wave_queue_report(WaveQueueCache &cache, float span_ms);
+WqVariant measured_choice(WaveQueueCache &cache, uint64_t key, double samples, const std::function<std::vector<WqVariant>()> &candidates);
 constexpr size_t kLdsSceneBytes = 40 * 1024;     // stage the traversal data in LDS when it is at most this big
 // `samples` must hold wave_queue_sample_bytes(frame) bytes (one float4 per pixel and frame of the launch); the launch
 // runs the tracing kernel and then the ordered resolve kernel on `stream`.
@@ -31,11 +35,11 @@ size_t wave_queue_scene_lds_bytes(const SceneView &scene);
 
 // path_pool (kernel_path_pool.hip): path state parked in LDS, phase-homogeneous batches of 64 paths; lean paths of scenes
 // whose traversal data fits LDS.  `status` is a device word the kernel sets when it had to abort (never hangs).
-bool path_pool_supports(const SceneView &scene, const FrameParams &frame, int bvh_depth, bool scene_has_alpha, size_t scene_lds_bytes);
+bool path_pool_supports(const SceneView &scene, const FrameParams &frame, int bvh_depth, size_t scene_lds_bytes, bool *hbm_scene);
 void path_pool_leaf_classes(const std::vector<LeafRange> &leaves, uint32_t out[3]);
 struct PoolTuning { int threads = 0, paths = 0, min_fill = 48, patience = 8, n_loop = 8, n_min_lanes = 16, cold_lds_kb = -1, share_grid = 1, dir_tries = 4; unsigned long long *stats = nullptr; };      // 0 = the launcher's default; stats: device u64[40] (DRT_POOL_STATS=1)
 struct PoolScratch { void *aux = nullptr, *aux_slot = nullptr, *aux_light = nullptr; size_t slots = 0; };     // HBM part of the path state, owned by the renderer
-hipError_t launch_path_pool(const SceneView &scene, const FrameParams &frame, int bvh_depth, bool scene_has_alpha, const uint32_t t_class[3], const PoolTuning &tune,
+hipError_t launch_path_pool(const SceneView &scene, const FrameParams &frame, int bvh_depth, bool scene_has_alpha, bool hbm_scene, const uint32_t t_class[3], const PoolTuning &tune,
                             PoolScratch &scratch, unsigned int *sample_counter, void *samples, unsigned int *status, int num_cus, hipStream_t stream, const char **kernel_name,
                             int *launch_shape /* out[5]: stack slots, workgroups per CU, LDS KiB, threads, pool paths */);
 

@@ -289,18 +289,22 @@ def test_external_buffers_and_stream():
     compare(rgba.cpu().numpy(), ref, "external buffers")
 
 
-def _render_with_env(env, name, W, H, frames, depth, **settings):
+def _renderer_with_env(env):
     import os
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
-        r = drt.Renderer(0)                     # the knobs are read when the renderer is created
+        return drt.Renderer(0)                  # the knobs are read when the renderer is created
     finally:
         for k, v in old.items():
             if v is None:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def _render_with_env(env, name, W, H, frames, depth, **settings):
+    r = _renderer_with_env(env)
     sc, osc = make_pair(name)
     cam, ocam = cameras(name)
     s, o = settings_pair(ray_bounce_limit=depth, **settings)
@@ -496,7 +500,7 @@ def test_edge_case_scenes_and_frame_sizes(renderer):
     assert sc.bvh_depth > 16
     img, ref = _render_both(renderer, sc, osc, (0.0, 0.5, 9.0), (0, -0.05, -1), 96, 54, 2, ray_bounce_limit=6)
     compare(img, ref, "soup depth %d" % sc.bvh_depth)
-    assert "hbm-scene" in renderer.kernelInfo() and "stack=%d" % sc.bvh_depth in renderer.kernelInfo()
+    assert renderer.kernelInfo().startswith("path_pool<lean+alpha,hbm-scene>") and "stack=%d " % (sc.bvh_depth - 1) in renderer.kernelInfo(), renderer.kernelInfo()
     img, ref = _render_both(renderer, sc, osc, (0.0, 0.5, 9.0), (0, -0.05, -1), 96, 54, 2, ray_bounce_limit=6, enableSunlight=1)
     compare(img, ref, "soup with sun shadows through cut-outs")
     # (2b) a small scene under a degenerate tree: 62 triangles whose centroids double in x peel off one per level (leaf size 1, two
@@ -595,14 +599,15 @@ def test_bench_two_rank_rehearsal_assembles_the_single_device_image():
 @pytest.mark.gpu
 def test_kernel_packaging_is_measured_not_guessed():
     """wave_queue has several legal packagings of a launch (workgroup size, stack entry bytes, triangles per T step; DESIGN.md 4 /
-    5.1).  They all compute the same image, so the renderer times each on its first big launches and keeps the fastest; scenes
-    whose traversal data fits LDS go to path_pool.  Checked: the image is the oracle's whatever is being tried, every candidate
-    gets its trials, and the one kept is the best measured (within 2 %)."""
+    5.2).  They all compute the same image, so the renderer times each on its first big launches and keeps the fastest (path_pool's
+    shape follows from what fits LDS).  Checked: the image is the oracle's whatever is being tried, every candidate gets its trials,
+    and the one kept is the best measured (within 2 %)."""
     expect = {"cornell_box": "path_pool<lean,lds-scene> stack=2 wg/CU=2 ",             # small LDS scene, lean paths: the path pool, two pools per CU
               "room": "path_pool<lean,lds-scene> stack=7 wg/CU=1 ",                    # 17.6 KB LDS scene, 8-level tree: one pool per CU
-              "cs16_dust": "wave_queue<lean,hbm-scene> stack=16",                      # deep tree from HBM: 8- or 6-byte stack entries, 2 or 3 triangles per step
-              "suzanne_plane": "wave_queue<lean,hbm-scene> stack=10"}
+              "cs16_dust": "path_pool<lean,hbm-scene> stack=15 wg/CU=1 threads=1024 ",  # tree read from global memory: 6-byte stack entries, one pool per CU
+              "suzanne_plane": "path_pool<lean,hbm-scene> stack=9 wg/CU=1 threads=1024 "}
     r = drt.Renderer(0)
+    r_wq = _renderer_with_env({"DRT_KERNEL": "wave_queue"})
     W, H = 160, 90
     r.ResizeBuffer(W, H)
     for name, marker in expect.items():
@@ -616,7 +621,8 @@ def test_kernel_packaging_is_measured_not_guessed():
         ref, _, _ = oracle.render(osc, ocam, o, W, H, 1, 2)
         compare(r.GetRenderTargetImage(), ref, name)
     assert all(p["chosen"] == -1 or len(p["candidates"]) == 1 for p in r.waveQueuePlans())      # 160x90 launches are too small to time
-    # big launches of one scene: every candidate is tried (bit-exact each time), then one is kept
+    # big launches of one scene on wave_queue: every candidate is tried (bit-exact each time), then one is kept
+    r = r_wq
     sc, osc = make_pair("cs16_dust")
     cam, ocam = cameras("cs16_dust")
     s, o = settings_pair(ray_bounce_limit=2, max_samples=1000)
@@ -641,10 +647,13 @@ def test_kernel_packaging_is_measured_not_guessed():
 @pytest.mark.gpu
 @pytest.mark.parametrize("kernel", ["path_pool", "wave_queue"])
 @pytest.mark.parametrize("name,W,H,frames,depth", [("cornell_box", 160, 90, 3, 8), ("room", 128, 72, 2, 16), ("bvh_split_test", 96, 64, 2, 4),
-                                                    ("cornell_box", 61, 37, 2, 0), ("room", 64, 64, 1, 32)])
+                                                    ("cornell_box", 61, 37, 2, 0), ("room", 64, 64, 1, 32),
+                                                    ("suzanne_plane", 160, 90, 2, 3), ("cs16_dust", 128, 72, 2, 5), ("dense_monkey", 96, 54, 2, 4),
+                                                    ("mc_transparency", 128, 72, 2, 5)])
 def test_both_tracing_kernels_match_the_oracle_on_lds_scenes(kernel, name, W, H, frames, depth):
-    """Scenes whose traversal data fits LDS are traced by path_pool (kernel_path_pool.hip: path state parked in LDS,
-    phase-homogeneous batches) unless DRT_KERNEL=wave_queue; both are bit-exact, partial tiles and long paths included."""
+    """Every scene is traced by path_pool (kernel_path_pool.hip: path state parked in LDS, phase-homogeneous batches; the
+    traversal data in LDS too where it fits, else read from global memory) unless DRT_KERNEL=wave_queue; both are bit-exact,
+    partial tiles and long paths included."""
     r, ref, ref_acc = _render_with_env({"DRT_KERNEL": kernel}, name, W, H, frames, depth)
     assert r.kernelInfo().startswith(kernel), r.kernelInfo()
     compare(r.GetRenderTargetImage(), ref, "%s %s" % (kernel, name))
@@ -668,13 +677,14 @@ def test_path_pool_scheduling_knobs_do_not_change_the_image(env):
 @pytest.mark.parametrize("kernel", ["path_pool", "wave_queue"])
 @pytest.mark.parametrize("name,W,H,frames,depth,sun", [("cornell_box", 128, 72, 2, 5, 1), ("room", 96, 54, 2, 8, 1), ("sunshadow_test", 128, 72, 2, 3, 1),
                                                         ("uv_texture_test", 128, 72, 2, 5, 0), ("uv_texture_test", 96, 54, 2, 4, 1),
-                                                        ("cornell_box", 64, 36, 1, 0, 1)])
+                                                        ("cornell_box", 64, 36, 1, 0, 1),
+                                                        ("cs16_dust", 96, 54, 2, 4, 1), ("mc_transparency", 96, 54, 2, 4, 1), ("suzanne_plane", 96, 54, 2, 2, 1)])
 def test_sunlight_and_alpha_cutouts_on_both_tracing_kernels(kernel, name, W, H, frames, depth, sun):
     """The sun's shadow ray (RayGen.cuh:124-128: RayTest, any accepted hit occludes) and the alpha test of AnyHit.cuh:8-28 in
     path_pool (shadow traversals ride the same N / T queues, S = the rest of the shading) and in wave_queue: the oracle's bits."""
     r, ref, ref_acc = _render_with_env({"DRT_KERNEL": kernel}, name, W, H, frames, depth, enableSunlight=sun)
     assert r.kernelInfo().startswith(kernel), r.kernelInfo()
-    want = "lean" + ("+alpha" if name == "uv_texture_test" else "") + ("+sun" if sun else "")
+    want = "lean" + ("+alpha" if name in ("uv_texture_test", "mc_transparency") else "") + ("+sun" if sun else "")
     assert "<%s," % want in r.kernelInfo(), r.kernelInfo()
     compare(r.GetRenderTargetImage(), ref, "%s %s sun=%d" % (kernel, name, sun))
     compare(r.GetAccumulationBuffer(), ref_acc, "%s %s accum" % (kernel, name))
@@ -682,8 +692,8 @@ def test_sunlight_and_alpha_cutouts_on_both_tracing_kernels(kernel, name, W, H, 
 
 @pytest.mark.gpu
 def test_path_pool_falls_back_where_it_does_not_apply():
-    """Debug views, scenes too big for LDS and the counting build stay on wave_queue."""
-    for name, kw in (("cornell_box", dict(RenderMode=1, DebugMode=1)), ("suzanne_plane", {}), ("cs16_dust", dict(enableSunlight=1))):
+    """Debug views (and the counting build, the material model: tests of their own) stay on wave_queue."""
+    for name, kw in (("cornell_box", dict(RenderMode=1, DebugMode=1)), ("suzanne_plane", dict(RenderMode=1, DebugMode=4)), ("cs16_dust", dict(RenderMode=1, DebugMode=0))):
         sc, osc = make_pair(name)
         cam, ocam = cameras(name)
         s, o = settings_pair(ray_bounce_limit=3, **kw)
