@@ -746,7 +746,9 @@ int drt_renderer_wait(drt_renderer *r, float *delta_ms) {
         HIP_TRY(hipMemcpy(&status, r->pool_status, sizeof status, hipMemcpyDeviceToHost));
         if (status != 0) {
             (void)hipMemset(r->pool_status, 0, sizeof status);
-            return fail(DRT_ERR_DEVICE, "path_pool kernel aborted (status " + std::to_string(status) + "): a queue wait exceeded its bound");
+            return fail(DRT_ERR_DEVICE, "path_pool kernel: status " + std::to_string(status) + (status < 0x100u ? " (a queue wait exceeded its bound; the launch was abandoned)"
+                                                                                                     : " (bits 8..: an index out of range was caught and clamped -- 0x100 triangle, 0x200 node, 0x400 leaf, "
+                                                                                                       "0x800 / 0x1000 hit triangle, 0x2000 material, 0x4000 texture, 0x8000 sample slot, 0x10000 / 0x20000 stack level)"));
         }
     }
     return DRT_OK;

@@ -215,6 +215,17 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         __syncthreads();
     }
 
+    // hbm-scene build (and every statistics build): an index that addresses global memory is range-checked first; a violation sets a
+    // status bit (8..: the host reports DRT_ERR_DEVICE with it) and the access goes to element 0 -- a logic error must not become a
+    // GPU memory fault, which can take the whole node down
+    // (branch-free -- a branch between the loads of a step would serialise them: the index is clamped, the violation noted in a
+    // register and reported once, after the batch)
+    uint32_t violations = 0;
+    auto checked = [&](uint32_t index, uint32_t limit, unsigned int code) -> uint32_t {
+        if (!(HBM || STATS)) return index;
+        violations |= index >= limit ? code : 0u;
+        return min(index, limit - 1u);
+    };
     // ---- the path's words: meta (flags, bounce index; + hit triangle in the lds-scene build, + stack height in the hbm-scene build) ----
     auto meta_at = [&](uint32_t id) -> uint32_t { return qW + id * kWordBytes; };
     auto bounce_of = [&](uint32_t meta) -> uint32_t { return HBM ? (meta & 0xFFFFu) : ((meta >> 12) & 0xFFFFu); };
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     auto fetch_tri = [&](int i) -> TriTest {
         const uint32_t q = lds_hot + __umul24((uint32_t)i, 48u);
         uint4 a, b; uint32_t c;
-        if (HBM) {
+        if (HBM) {                                   // (i: range-checked by the caller, once per batch)
             const uint4 *g = reinterpret_cast<const uint4 *>(sc.tri_hot) + (size_t)i * 3;
             a = g[0]; b = g[1]; c = reinterpret_cast<const uint32_t *>(g)[8];
         } else { a = ld4(q); b = ld4(q + 16); c = ld1(q + 32); }
@@ -244,6 +255,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         const uint32_t q = lds_inner + index * 64u;
         uint4 a, b, c; uint2 r;
         if (HBM) {
+            index = checked(index, sc.n_inner, 0x200u);
             const uint4 *g = reinterpret_cast<const uint4 *>(sc.inner) + (size_t)index * 4;
             a = g[0]; b = g[1]; c = g[2]; r = *reinterpret_cast<const uint2 *>(g + 3);
         } else { a = ld4(q); b = ld4(q + 16); c = ld4(q + 32); r = ld2(q + 48); }
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         return p;
     };
     auto fetch_face_normal = [&](int prim) -> f3 {
-        if (HBM) return ld3(sc.tri_hot[prim].fn);
+        if (HBM) return ld3(sc.tri_hot[prim].fn);    // (prim: range-checked by the caller)
         const uint32_t q = lds_hot + __umul24((uint32_t)prim, 48u) + 36u;
         return mk3(u2f(ld1(q)), u2f(ld1(q + 4)), u2f(ld1(q + 8)));
     };
@@ -268,13 +280,13 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         return c;
     };
     auto fetch_mat = [&](int index) -> MatDev {
-        if (!cold_lds) return sc.mats[index];
+        if (!cold_lds) return sc.mats[checked((uint32_t)index, sc.n_mats, 0x2000u)];
         const uint4 a = ld4(lds_mats + (uint32_t)index * 16u);
         MatDev m; m.albedo[0] = u2f(a.x); m.albedo[1] = u2f(a.y); m.albedo[2] = u2f(a.z); m.tex = (int32_t)a.w;
         return m;
     };
     auto fetch_tex = [&](int index) -> TexDev {
-        if (!cold_lds) return sc.texs[index];
+        if (!cold_lds) return sc.texs[checked((uint32_t)index, sc.n_texs, 0x4000u)];
         const uint4 a = ld4(lds_texs + (uint32_t)index * 16u);
         TexDev t; t.width = (int32_t)a.x; t.height = (int32_t)a.y; t.comps = (int32_t)a.z; t.offset = a.w;
         return t;
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     // build (the staged records carry it), the leaf's index in the hbm-scene build
     auto leaf_state = [&](uint32_t leaf_ref, uint32_t &cur, uint32_t &end) -> int {
         uint32_t count;
-        if (HBM) { const LeafRange lr = sc.leaves[leaf_ref]; cur = (uint32_t)lr.start; count = (uint32_t)lr.count; }
+        if (HBM) { const LeafRange lr = sc.leaves[checked(leaf_ref, sc.n_leaves, 0x400u)]; cur = (uint32_t)lr.start; count = (uint32_t)lr.count; }
         else { cur = leaf_ref & 0xFFFu; count = leaf_ref >> 12; }
         end = cur + count;
         const uint32_t steps = (count + 1u) >> 1;
@@ -297,13 +309,13 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     // 6 bytes, a quarter more paths per CU (path_pool_supports: fewer than 32768 interior nodes and leaves)
     const uint32_t stack_refs = stack + pp.stack_entries * P * 4u;
     auto stack_load = [&](int level, uint32_t id) -> uint2 {
-        const uint32_t at = (uint32_t)level * P + id;
+        const uint32_t at = (STATS ? checked((uint32_t)level, pp.stack_entries, 0x10000u) : (uint32_t)level) * P + id;   // (LDS: cannot fault)
         if (!HBM) return ld2(stack + at * 8u);
         const uint32_t r16 = ld_u16(stack_refs + at * 2u);
         return make_uint2((r16 & 0x8000u) ? (kLeafBit | (r16 & 0x7FFFu)) : r16, ld1(stack + at * 4u));
     };
     auto stack_store = [&](int level, uint32_t id, uint2 e) {
-        const uint32_t at = (uint32_t)level * P + id;
+        const uint32_t at = (STATS ? checked((uint32_t)level, pp.stack_entries, 0x20000u) : (uint32_t)level) * P + id;
         if (!HBM) { st2(stack + at * 8u, e); return; }
         st_u16(stack_refs + at * 2u, (e.x & kLeafBit) ? (0x8000u | (e.x & 0x7FFFu)) : e.x);
         st1(stack + at * 4u, e.y);
@@ -573,7 +585,11 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 ray.orig = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); hit_t = u2f(A.w);
                 ray.dir = mk3(u2f(B.x), u2f(B.y), u2f(B.z));
                 if (HBM || SUN) meta = ld1(meta_at(id));
-                if (HBM) { cur = (int)B.w; end = (int)ld1(meta_at(id) + 8u); sp = (int)((meta >> 16) & 0xFFu); }
+                if (HBM) {
+                    end = (int)(checked(ld1(meta_at(id) + 8u) - 1u, sc.n_tris, 0x100u) + 1u);         // [cur, end) within the triangles
+                    cur = (int)min(B.w, (uint32_t)end);
+                    sp = (int)((meta >> 16) & 0xFFu);
+                }
                 else { cur = (int)(B.w & 0xFFFu); end = (int)((B.w >> 12) & 0xFFFu); sp = (int)(B.w >> 24); }
                 if (SUN) shadow = (meta & kShadow) != 0;
             }
@@ -657,7 +673,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 const uint32_t W = ld1(meta_at(id));
                 Ray ray; ray.orig = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); ray.dir = mk3(u2f(B.x), u2f(B.y), u2f(B.z)); ray.inv_dir = ray.dir;
                 const float hit_t = u2f(A.w);
-                const int hit_prim = (int)prim_of(id, W);
+                const int hit_prim = HBM ? (int)checked(prim_of(id, W), sc.n_tris, 0x800u) : (int)prim_of(id, W);
                 uint32_t bounce = bounce_of(W);
                 // the barycentrics of the hit: the winning triangle's test once more (same inputs, same bits as in T)
                 float hit_u, hit_v, t_again;
@@ -704,7 +720,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 }
                 const uint32_t bounce = bounce_of(W) + 1u;
                 if ((int)bounce <= fp.bounce_limit) {                                      // :88 loop condition
-                    const f3 fn = fetch_face_normal((int)prim_of(id, W));
+                    const f3 fn = fetch_face_normal(HBM ? (int)checked(prim_of(id, W), sc.n_tris, 0x1000u) : (int)prim_of(id, W));
                     need_dir = true; dir_origin = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); dir_normal = (W & kBackFace) ? (-1.f * fn) : fn;
                     dir_seed = E.w; dir_bounce = bounce; dir_tries = 0;
                 } else {
@@ -728,8 +744,9 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                         light = light + sky_model(mk3(u2f(B.x), u2f(B.y), u2f(B.z)), ld3(fp.sky_color)) * mk3(u2f(E.x), u2f(E.y), u2f(E.z)) * fp.sky_intensity;
                     if (fp.tone_mapping) light = uncharted2_filmic(light, fp.exposure);    // :165-169 (wave-uniform branches)
                     if (fp.gamma_correction) light = gamma_correction(light);
-                    if (fp.inline_resolve) accumulate_and_resolve(fp, slot, light);        // one frame in the launch: slot = pixel
-                    else samples[slot] = make_float4(light.x, light.y, light.z, 0.0f);
+                    const uint32_t slot_ok = checked(slot, fp.width * fp.local_rows * fp.n_frames, 0x8000u);
+                    if (fp.inline_resolve) accumulate_and_resolve(fp, slot_ok, light);     // one frame in the launch: slot = pixel
+                    else samples[slot_ok] = make_float4(light.x, light.y, light.z, 0.0f);
                 }
             }
             // Sample ids.  The first P of a workgroup are fixed (workgroup w starts with [w*P, (w+1)*P): the slots that wait in E's
@@ -780,6 +797,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         }
         lds_release();
         push_group(dest, id);
+        if ((HBM || STATS) && pp_ballot(violations != 0) != 0) { if (violations != 0 && pp.status) atomicOr(pp.status, violations); violations = 0; }
         if (STATS) s_ticks[q] += __builtin_amdgcn_s_memtime() - s_t1;
     }
 
