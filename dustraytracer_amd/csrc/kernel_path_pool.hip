@@ -226,6 +226,8 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         violations |= index >= limit ? code : 0u;
         return min(index, limit - 1u);
     };
+    // (the lds-scene production build goes without: its indices are 12-bit fields of LDS words, its record over some 10^5 launches
+    // is clean, and the checks -- even only those of the shading phases -- cost room 1.2 %)
     // ---- the path's words: meta (flags, bounce index; + hit triangle in the lds-scene build, + stack height in the hbm-scene build) ----
     auto meta_at = [&](uint32_t id) -> uint32_t { return qW + id * kWordBytes; };
     auto bounce_of = [&](uint32_t meta) -> uint32_t { return HBM ? (meta & 0xFFFFu) : ((meta >> 12) & 0xFFFFu); };
@@ -673,7 +675,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 const uint32_t W = ld1(meta_at(id));
                 Ray ray; ray.orig = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); ray.dir = mk3(u2f(B.x), u2f(B.y), u2f(B.z)); ray.inv_dir = ray.dir;
                 const float hit_t = u2f(A.w);
-                const int hit_prim = HBM ? (int)checked(prim_of(id, W), sc.n_tris, 0x800u) : (int)prim_of(id, W);
+                const int hit_prim = (int)checked(prim_of(id, W), sc.n_tris, 0x800u);
                 uint32_t bounce = bounce_of(W);
                 // the barycentrics of the hit: the winning triangle's test once more (same inputs, same bits as in T)
                 float hit_u, hit_v, t_again;
@@ -720,7 +722,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 }
                 const uint32_t bounce = bounce_of(W) + 1u;
                 if ((int)bounce <= fp.bounce_limit) {                                      // :88 loop condition
-                    const f3 fn = fetch_face_normal(HBM ? (int)checked(prim_of(id, W), sc.n_tris, 0x1000u) : (int)prim_of(id, W));
+                    const f3 fn = fetch_face_normal((int)checked(prim_of(id, W), sc.n_tris, 0x1000u));
                     need_dir = true; dir_origin = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); dir_normal = (W & kBackFace) ? (-1.f * fn) : fn;
                     dir_seed = E.w; dir_bounce = bounce; dir_tries = 0;
                 } else {
