@@ -874,6 +874,9 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     // in registers and is spilled only where it is an interior node, so never more than levels - 1 entries.  (Smaller entries were
     // tried on room, where 64 more paths in the pool are worth 3-5 %: 6 bytes {distance, parent << 1 | which child} cost 3.5 % at
     // equal pool size and end level at 1408 paths against 1216; 2 bytes with the distance computed again at the pop cost 7 %.)
+    // (And once more after the hbm-scene build had them: 6-byte entries {distance, 16-bit reference} with the leaf ranges back in an
+    // LDS table -- room 1408 paths, 44.0 ms against 43.6 with 8-byte entries and 1216 paths; cornell's pools come out as 3 x 704, 3.63 ms
+    // against 3.47.  The lds-scene build keeps its 8-byte entries.)
     // (Rings of exactly P entries instead of the next power of two -- positions counted modulo a multiple of P, slot = position
     // mod P by multiplication -- were tried too: room's pool grows from 1216 to 1344 paths, and the extra arithmetic in every claim
     // and push costs the 3 % that buys.)
