@@ -123,7 +123,7 @@ def test_debug_views(renderer, mode):
                                 dict(gamma_correction=0), dict(tone_mapping=0, gamma_correction=0),
                                 dict(ray_bounce_limit=0), dict(ray_bounce_limit=-1), dict(sky_intensity=3.5, sky_color=(0.6, 0.7, 1.0))])
 def test_settings_variants(renderer, kw):
-    for name in ("room", "cornell_box"):
+    for name in ("room", "cornell_box", "suzanne_plane", "mc_transparency"):      # lds-scene and hbm-scene builds, with and without cut-outs
         sc, osc = make_pair(name)
         cam, ocam = cameras(name)
         s, o = settings_pair(**kw)
