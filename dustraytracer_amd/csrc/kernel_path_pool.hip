@@ -437,6 +437,10 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     unsigned long long s_t0 = s_t_start;
     for (;;) {
         if (STATS) s_t0 = __builtin_amdgcn_s_memtime();
+        // (lds-scene build: a wave that is claiming or pushing goes ahead of the waves inside a phase -- these are short chains of LDS
+        // round trips, and the sooner they are through the sooner 64 more lanes have work: room -2 %, cornell -1 %; the hbm-scene
+        // build, which waits for L2 everywhere, loses 1 % with it)
+        if (!HBM) __builtin_amdgcn_s_setprio(1);
         // ---------------- choose a queue and claim up to 64 of its ids ----------------
         // Queues holding a full batch are shared out round robin (the waves of a workgroup would otherwise all race for
         // the same one); with none, the fullest queue is taken -- after a short wait for company unless the launch is draining.
@@ -515,6 +519,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         lds_acquire();
         unsigned long long s_t1 = 0;
         if (STATS) { s_t1 = __builtin_amdgcn_s_memtime(); s_claim += s_t1 - s_t0; s_batches[q]++; s_lanes[q] += n; }
+        if (!HBM) __builtin_amdgcn_s_setprio(0);
         int dest = -1;                                                    // queue this lane's path goes to next
         // bounce direction being drawn (B, R): randomUnitSphereVec3 is a rejection loop (Random.cu:50-58, ~2.9 candidates on
         // average, a long tail); a batch draws at most pp.dir_tries candidates per path with every lane that still needs one,
@@ -797,6 +802,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 }
             }
         }
+        if (!HBM) __builtin_amdgcn_s_setprio(1);
         lds_release();
         push_group(dest, id);
         if ((HBM || STATS) && pp_ballot(violations != 0) != 0) { if (violations != 0 && pp.status) atomicOr(pp.status, violations); violations = 0; }
