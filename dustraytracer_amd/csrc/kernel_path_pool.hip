@@ -1,22 +1,28 @@
-// kernel_path_pool.hip -- "path_pool": the tracing kernel for scenes whose traversal data lives in LDS, with the
-// PATH STATE parked in LDS too and every phase run for 64 paths that all need exactly that phase.
+// kernel_path_pool.hip -- "path_pool": the tracing kernel.  The PATH STATE is parked in LDS and every phase is run for 64 paths
+// that all need exactly that phase; the traversal data lives in LDS too where it fits (lds-scene build), else it is read from
+// global memory (hbm-scene build).
 //
 // wave_queue (kernel_wave_queue.hip) keeps one path per lane in registers and lets the 64 lanes of a wave vote on the
 // phase to run next; its counters say half of every vector instruction is masked-off lanes (profiles/
 // r01_wave_queue_pmc_sq.txt: lane utilisation 0.51) because at any moment the lanes of a wave want different things.
-// Here a lane owns nothing.  A workgroup (one per CU) keeps a POOL of P paths (P ~ 2-3 x its lanes) in LDS, and every
+// Here a lane owns nothing.  A workgroup keeps a POOL of P paths (P ~ 1-1.4 x its lanes, as many as LDS holds), and every
 // path waits in exactly one queue:
-//     N      pop one entry of its traversal stack; interior node: slab-test both children, push     BVHTraversal.cuh:33-72
-//     T0..T3 test the triangles of the leaf it stands on, two per step (one queue per leaf-size class,
-//            so that the lanes of a batch run the same number of steps)                             BVHTraversal.cuh:46-57
+//     N      pop entries of its traversal stack; interior node: slab-test both children, push       BVHTraversal.cuh:33-72
+//     T0..T3 test the triangles of the leaf it stands on, two (hbm-scene: four) per step -- one queue per
+//            leaf-size class, so that the lanes of a batch run the same number of steps              BVHTraversal.cuh:46-57
 //     B      shade the closest hit, draw the bounce direction (a few candidates), launch the bounce ray  RayGen.cuh:90-134
+//            (sunlight builds: launch the sun's shadow ray instead -- a traversal through N and T without culls whose
+//            first accepted hit ends it, BVHTraversal.cuh:76-134)
+//     S      sunlight builds: after the shadow traversal, add the sunlight, then the direction and the bounce ray  RayGen.cuh:126-134
 //     R      more candidates for the paths whose direction was still rejected, then launch             Random.cu:50-58
 //     E      finish the path (sky term, tone map, gamma, store the sample), take a new sample,
 //            generate its primary ray                                                               RayGen.cuh:63-108,165-171
 // A wave claims up to 64 path ids of ONE queue, loads the part of the state that phase needs, runs the phase with every
 // lane busy, stores what changed and pushes each id to the queue of its next phase.  State per path: 36 bytes of LDS
-// (A {origin, hit distance}, B {direction, leaf range | stack height}, W {hit triangle | bounce | flag}) + its traversal
-// stack (8 bytes per BVH level); throughput, RNG state and the sample's slot -- touched by B and E only -- live in HBM.  Per-lane order of node visits, triangle tests and RNG draws is the reference's, and the arithmetic is the
+// (A {origin, hit distance}, B {direction, leaf range | stack height}, W {hit triangle | bounce | flags}; 48 bytes with
+// 32-bit triangle indices in the hbm-scene build) + its traversal stack (8 bytes per BVH level below the root; 6 in the
+// hbm-scene build); throughput, RNG state, the sample's slot and the light gathered so far -- touched by the shading phases
+// only -- live in HBM.  Per-lane order of node visits, triangle tests and RNG draws is the reference's, and the arithmetic is the
 // same device_math.hpp code as wave_queue's, so the image is bit-identical; only who computes what when differs.
 //
 // Queues are rings of 16-bit path ids in LDS, multi-producer / multi-consumer inside the workgroup: a producer reserves a
@@ -24,7 +30,8 @@
 // [head, head+n) with one compare-and-swap on the head, reads the ids (an entry still 0xFFFF = reserved but not written
 // yet: re-read) and empties the slots.  Every wait is on a strictly older ring position, so there is no cycle.
 // Every wait in this kernel is bounded: a wave that polls too long raises the abort flag, all waves leave, the host
-// reports DRT_ERR_DEVICE (status word) -- a logic error must never hang the GPU.
+// reports DRT_ERR_DEVICE (status word) -- a logic error must never hang the GPU; the hbm-scene build also clamps every
+// index it addresses global memory with (a violation is reported the same way instead of faulting).
 // No MFMA (branchy scalar fp32 / u32).  Citations are relative to /root/reference/DustRayTracer/src/.
 #include <hip/hip_runtime.h>
 
