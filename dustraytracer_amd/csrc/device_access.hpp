@@ -19,8 +19,18 @@ DRT_DEV uint32_t texel_index(const TexDev &tex, f2 uv) {               // Textur
     return (uint32_t)(y * tex.width + x);
 }
 
+// CLAMP (path_pool's hbm-scene and statistics builds): the texel index is held to the texture's padded extent -- width * height
+// texels + the (width + 1) zero texels the packer appends for the latent out-of-bounds read of Texture.cu:35-49 -- which a valid
+// header and any uv (finite, infinite or NaN) already guarantee: x <= width, y <= height.  Defence in depth, no effect on the value.
+template <bool CLAMP>
+DRT_DEV uint32_t texel_index_in(const TexDev &tex, f2 uv) {
+    const uint32_t i = texel_index(tex, uv);
+    return CLAMP ? min(i, (uint32_t)(tex.width * tex.height + tex.width)) : i;
+}
+
+template <bool CLAMP = false>
 DRT_DEV f3 tex_get_pixel(const SceneView &sc, const TexDev &tex, f2 uv) {          // Texture.cu:33-58
-    uint32_t i = texel_index(tex, uv);
+    uint32_t i = texel_index_in<CLAMP>(tex, uv);
     float r = 0, g = 0, b = 255;
     if (tex.comps == 3 || tex.comps == 4) {
         const uint8_t *p = sc.texels + tex.offset + (size_t)i * (uint32_t)tex.comps;
@@ -30,9 +40,10 @@ DRT_DEV f3 tex_get_pixel(const SceneView &sc, const TexDev &tex, f2 uv) {       
     return mk3(c.x * c.x, c.y * c.y, c.z * c.z);
 }
 
+template <bool CLAMP = false>
 DRT_DEV float tex_get_alpha(const SceneView &sc, const TexDev &tex, f2 uv) {       // Texture.cu:60-75
     if (tex.comps < 4) return 1;
-    uint32_t i = texel_index(tex, uv);
+    uint32_t i = texel_index_in<CLAMP>(tex, uv);
     return sc.texels[tex.offset + (size_t)i * 4u + 3u] / (float)255;
 }
 

@@ -105,6 +105,8 @@ struct drt_renderer {
     bool use_pixel_walk = false;              // DRT_KERNEL=pixel_walk selects the first (non-persistent) kernel
     int use_path_pool = 1;                    // path_pool where it applies (lean paths, scene in LDS); DRT_KERNEL=wave_queue: never
     unsigned int *pool_status = nullptr;      // device word: set by an aborted path_pool launch
+    unsigned int *pool_status_host = nullptr; // pinned host word: the device word as of the end of the last batch (copied on the stream, before ev_stop)
+    bool pool_launched = false;               // the batch in flight launched path_pool at least once
     WaveQueueCache wq_cache;                  // measured choice among wave_queue's launch packagings
     PoolScratch pool_scratch;
     PoolTuning pool_tuning;                   // DRT_POOL_THREADS / _PATHS / _MIN_FILL / _PATIENCE
@@ -376,7 +378,8 @@ drt_renderer *drt_renderer_create(int32_t device) {
         hipMalloc((void **)&r->tile_counter, sizeof(unsigned int) * drt_renderer::kCounters) != hipSuccess ||
         hipMemset(r->tile_counter, 0, sizeof(unsigned int) * drt_renderer::kCounters) != hipSuccess ||
         hipMalloc((void **)&r->pool_status, sizeof(unsigned int)) != hipSuccess ||
-        hipMemset(r->pool_status, 0, sizeof(unsigned int)) != hipSuccess) {
+        hipMemset(r->pool_status, 0, sizeof(unsigned int)) != hipSuccess ||
+        hipHostMalloc((void **)&r->pool_status_host, sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) {
         fail(DRT_ERR_DEVICE, "cannot create HIP events / counter buffer");
         drt_renderer_destroy(r);
         return nullptr;
@@ -394,6 +397,7 @@ void drt_renderer_destroy(drt_renderer *r) {
     if (r->spans) (void)hipFree(r->spans);
     if (r->tile_counter) (void)hipFree(r->tile_counter);
     if (r->pool_status) (void)hipFree(r->pool_status);
+    if (r->pool_status_host) (void)hipHostFree(r->pool_status_host);
     if (r->pool_tuning.stats) (void)hipFree(r->pool_tuning.stats);
     if (r->pool_scratch.aux) (void)hipFree(r->pool_scratch.aux);
     if (r->pool_scratch.aux_slot) (void)hipFree(r->pool_scratch.aux_slot);
@@ -647,6 +651,7 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
     if (!r || !cam || !scene) return fail(DRT_ERR_INVALID, "null argument");
     if (delta_ms) *delta_ms = 0.f;
     r->pending = false;
+    r->pool_launched = false;
     if (r->width == 0 || r->height == 0) return fail(DRT_ERR_INVALID, "ResizeBuffer has not been called");
     // Renderer.cu:82: nothing happens once m_FrameIndex == max_samples, so at most max_samples-1 frames accumulate.
     if ((int64_t)r->frame_index == (int64_t)r->settings.max_samples) return DRT_OK;
@@ -695,7 +700,7 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
             unsigned int *const queue_head = r->tile_counter + r->counters_used++;
             bool pool_hbm_scene = false;
             if (r->use_path_pool && !r->counting && !material_ext &&
-                path_pool_supports(r->view, fp, r->bvh_depth, wave_queue_scene_lds_bytes(r->view), &pool_hbm_scene))
+                path_pool_supports(r->view, fp, r->bvh_depth, wave_queue_scene_lds_bytes(r->view), &pool_hbm_scene) && (r->pool_launched = true))
                 HIP_TRY(launch_path_pool(r->view, fp, r->bvh_depth, r->scene_has_alpha, pool_hbm_scene, r->pool_t_class, r->pool_tuning, r->pool_scratch, queue_head, r->samples, r->pool_status,
                                          r->num_cus, r->stream, &r->kernel_name, r->launch_shape));
             else
@@ -703,6 +708,9 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
                                       r->samples, r->num_cus, r->stream, &r->kernel_name, r->launch_shape, r->wq_cache));
         }
     }
+    // the kernel's status word travels to pinned host memory on the stream: drt_renderer_wait reads it after the event, no
+    // second round trip to the device (a 1/8-shard step is 0.4 ms)
+    if (r->pool_launched) { HIP_TRY(hipMemcpyAsync(r->pool_status_host, r->pool_status, sizeof(unsigned int), hipMemcpyDeviceToHost, r->stream)); }
     HIP_TRY(hipEventRecord(r->ev_stop, r->stream));                    // Renderer.cu:105
     r->frame_index += n_frames;                                        // Renderer.cu:116
     r->pending = true;
@@ -741,14 +749,15 @@ int drt_renderer_wait(drt_renderer *r, float *delta_ms) {
     }
     wave_queue_report(r->wq_cache, r->span_ms);
     r->pending = false;
-    if (r->use_path_pool) {
-        unsigned int status = 0;
-        HIP_TRY(hipMemcpy(&status, r->pool_status, sizeof status, hipMemcpyDeviceToHost));
+    if (r->pool_launched) {
+        const unsigned int status = *r->pool_status_host;      // (copied on the stream before ev_stop)
+        r->pool_launched = false;
         if (status != 0) {
             (void)hipMemset(r->pool_status, 0, sizeof status);
             return fail(DRT_ERR_DEVICE, "path_pool kernel: status " + std::to_string(status) + (status < 0x100u ? " (a queue wait exceeded its bound; the launch was abandoned)"
                                                                                                      : " (bits 8..: an index out of range was caught and clamped -- 0x100 triangle, 0x200 node, 0x400 leaf, "
-                                                                                                       "0x800 / 0x1000 hit triangle, 0x2000 material, 0x4000 texture, 0x8000 sample slot, 0x10000 / 0x20000 stack level)"));
+                                                                                                       "0x800 / 0x1000 hit triangle, 0x2000 material, 0x4000 texture, 0x8000 sample slot, 0x10000 / 0x20000 stack level, "
+                                                                                                       "0x40000 path id from a queue, 0x80000 shading record)"));
         }
     }
     return DRT_OK;

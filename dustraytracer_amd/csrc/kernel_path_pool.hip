@@ -25,10 +25,16 @@
 // only -- live in HBM.  Per-lane order of node visits, triangle tests and RNG draws is the reference's, and the arithmetic is the
 // same device_math.hpp code as wave_queue's, so the image is bit-identical; only who computes what when differs.
 //
-// Queues are rings of 16-bit path ids in LDS, multi-producer / multi-consumer inside the workgroup: a producer reserves a
-// position with an atomic add on the tail and writes the id there once the slot is empty (0xFFFF); a consumer claims
-// [head, head+n) with one compare-and-swap on the head, reads the ids (an entry still 0xFFFF = reserved but not written
-// yet: re-read) and empties the slots.  Every wait is on a strictly older ring position, so there is no cycle.
+// Queues are rings of 16-bit entries in LDS, multi-producer / multi-consumer inside the workgroup.  An entry is
+// path id (12 bits, P <= 4032) | lap of its ring position (position / ring capacity, 4 bits) << 12; 0xFFFF = empty.
+// A producer reserves a position with an atomic add on the tail and writes its entry there once the slot is empty; a consumer
+// claims [head, head+n) with one compare-and-swap on the head, reads the entries -- accepting only an entry that carries the
+// lap of ITS position (anything else is re-read: empty = reserved but not written yet, another lap's tag = the entry of the
+// position one lap earlier, whose consumer has claimed it but not taken it yet) -- and empties the slots.  Both directions are
+// closed that way: a producer never overwrites an entry that has not been taken (round 2 had that), and a consumer never takes
+// the entry of an earlier lap (round 2 did not: a wave stalled between its claim and its read while the other paths cycled
+// the ring once could see its entry taken twice -- one path in two queues; tools/sim_queue.py --ring-hazard replays it).
+// Every wait is on a strictly older ring position, so there is no cycle.
 // Every wait in this kernel is bounded: a wave that polls too long raises the abort flag, all waves leave, the host
 // reports DRT_ERR_DEVICE (status word) -- a logic error must never hang the GPU; the hbm-scene build also clamps every
 // index it addresses global memory with (a violation is reported the same way instead of faulting).
@@ -49,7 +55,9 @@ namespace {
 
 constexpr int kNQ = 9;                               // queues: N, T0..T3, B, E, R, S
 enum : int { QN = 0, QT0 = 1, QB = 5, QE = 6, QR = 7, QS = 8 };
-constexpr uint32_t kEmptyId = 0xFFFFu;
+constexpr uint32_t kEmptyId = 0xFFFFu;                // ring entry: path id | (lap & 15) << 12; ids stop at 4031, so 0xFFFF is never an entry
+constexpr uint32_t kIdMask = 0xFFFu;
+constexpr uint32_t kMaxPoolPaths = 4032u;
 constexpr uint32_t kNoPrim = 0xFFFu;                 // word W: hit triangle (12 bits, kNoPrim = none) | bounce index << 12 (16 bits) | kHasSample
 constexpr uint32_t kHasSample = 1u << 28;
 constexpr uint32_t kShadow = 1u << 29;               // the traversal under way is the sun's shadow ray (RayTest, BVHTraversal.cuh:76-134)
@@ -144,6 +152,7 @@ __host__ __device__ inline uint32_t pool_cold_bytes(const SceneView &sc) { retur
 struct PoolParams {
     uint32_t P;                // paths in the pool (multiple of 64)
     uint32_t ring_cap;         // entries per ring: power of two >= P
+    uint32_t ring_shift;       // log2(ring_cap): ring position >> ring_shift = the lap, whose low 4 bits tag the entry
     uint32_t stack_entries;    // BVH levels - 1
     uint32_t total_samples;    // n_chunks * 64 (sample ids beyond the image edge are skipped)
     uint32_t n_chunks, tiles_x;
@@ -215,7 +224,10 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         }
         for (uint32_t i = tid; i < kRings * pp.ring_cap; i += wg) st_id(rings + i * 2u, kEmptyId);
         for (uint32_t i = tid; i < 32u; i += wg) st1(ctrl + i * 4u, 0u);
-        for (uint32_t i = tid; i < P; i += wg) st1(qW + i * kWordBytes, HBM ? 0u : kNoPrim);       // no sample yet
+        for (uint32_t i = tid; i < P; i += wg) {                                                  // no sample yet
+            if (HBM) st4(qW + i * 16u, make_uint4(0u, 0u, 0u, 0u));                                // {meta, hit triangle, leaf end, -}: all of it
+            else st1(qW + i * 4u, kNoPrim);
+        }
         __syncthreads();
         for (uint32_t i = tid; i < P; i += wg) st_id(rings + ((uint32_t)QE * pp.ring_cap + i) * 2u, i);
         if (tid == 0) { st1(ctrl + QE * 8u + 4u, P); st1(ctrl + kCtrlLive, P); }
@@ -233,8 +245,13 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         violations |= index >= limit ? code : 0u;
         return min(index, limit - 1u);
     };
-    // (the lds-scene production build goes without: its indices are 12-bit fields of LDS words, its record over some 10^5 launches
-    // is clean, and the checks -- even only those of the shading phases -- cost room 1.2 %)
+    // (the lds-scene production build: its traversal indices are 12-bit fields of LDS words and address LDS, which cannot fault;
+    // the reporting checks -- even only those of the shading phases -- cost room 1.2 %.  What it reads from GLOBAL memory -- the
+    // shading records of scenes whose cold data is not staged, the texels, the HBM part of the path state -- is addressed through
+    // `held`: clamped, not reported; the path id itself is checked where it is claimed.)
+    auto held = [&](uint32_t index, uint32_t limit, unsigned int code) -> uint32_t {
+        return (HBM || STATS) ? checked(index, limit, code) : min(index, limit - 1u);
+    };
     // ---- the path's words: meta (flags, bounce index; + hit triangle in the lds-scene build, + stack height in the hbm-scene build) ----
     auto meta_at = [&](uint32_t id) -> uint32_t { return qW + id * kWordBytes; };
     auto bounce_of = [&](uint32_t meta) -> uint32_t { return HBM ? (meta & 0xFFFFu) : ((meta >> 12) & 0xFFFFu); };
@@ -280,7 +297,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         return mk3(u2f(ld1(q)), u2f(ld1(q + 4)), u2f(ld1(q + 8)));
     };
     auto fetch_cold = [&](int prim) -> TriCold {
-        if (!cold_lds) return sc.tri_cold[prim];
+        if (!cold_lds) return sc.tri_cold[held((uint32_t)prim, sc.n_tris, 0x80000u)];
         const uint32_t q = lds_cold + (uint32_t)prim * 32u;
         const uint4 a = ld4(q), b = ld4(q + 16);
         TriCold c;
@@ -289,16 +306,28 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         return c;
     };
     auto fetch_mat = [&](int index) -> MatDev {
-        if (!cold_lds) return sc.mats[checked((uint32_t)index, sc.n_mats, 0x2000u)];
+        if (!cold_lds) return sc.mats[held((uint32_t)index, sc.n_mats, 0x2000u)];
         const uint4 a = ld4(lds_mats + (uint32_t)index * 16u);
         MatDev m; m.albedo[0] = u2f(a.x); m.albedo[1] = u2f(a.y); m.albedo[2] = u2f(a.z); m.tex = (int32_t)a.w;
         return m;
     };
     auto fetch_tex = [&](int index) -> TexDev {
-        if (!cold_lds) return sc.texs[checked((uint32_t)index, sc.n_texs, 0x4000u)];
+        if (!cold_lds) return sc.texs[held((uint32_t)index, sc.n_texs, 0x4000u)];
         const uint4 a = ld4(lds_texs + (uint32_t)index * 16u);
         TexDev t; t.width = (int32_t)a.x; t.height = (int32_t)a.y; t.comps = (int32_t)a.z; t.offset = a.w;
         return t;
+    };
+    // AnyHit (AnyHit.cuh:8-28) through the readers above: the records come from LDS where they are staged, and in the hbm-scene
+    // build the material and texture indices (read from global memory) are range-checked like every other index; same arithmetic
+    // as device_access.hpp any_hit
+    auto alpha_test = [&](int prim, f3 uvw) -> bool {
+        const TriCold cold = fetch_cold(prim);                   // (prim: range-checked by the caller)
+        const MatDev mat = fetch_mat(cold.material);
+        if (mat.tex < 0) return true;
+        const TexDev tex = fetch_tex(mat.tex);
+        if (tex.comps < 4) return true;
+        const float alpha = tex_get_alpha<true>(sc, tex, interp_uv(cold, uvw));
+        return !(alpha < 1);
     };
     // leaf -> its triangles [cur, end) and the T queue of its size class.  leaf_ref: count << 12 | first triangle in the lds-scene
     // build (the staged records carry it), the leaf's index in the hbm-scene build
@@ -380,14 +409,15 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         if (dest >= 0 && lane == my_leader) base = lds_add(ctrl + (uint32_t)dest * 8u + 4u, add_count);
         base = (uint32_t)__builtin_amdgcn_ds_bpermute(my_leader << 2, (int)base);
         if (dest >= 0) {
-            // The slot may still hold the id of the previous lap: its consumer has claimed it (at most P <= ring_cap ids are ever
+            // The slot may still hold the entry of the previous lap: its consumer has claimed it (at most P <= ring_cap ids are ever
             // outstanding, so the head is past it) but may not have read and cleared it yet -- at the start, when E's ring holds
             // all P ids, a path that goes straight back to E lands on exactly such a slot.  Wait for the slot to be empty.
-            const uint32_t at = rings + ((uint32_t)dest * pp.ring_cap + ((base + my_rank) & ring_mask)) * 2u;
+            const uint32_t pos = base + my_rank;
+            const uint32_t at = rings + ((uint32_t)dest * pp.ring_cap + (pos & ring_mask)) * 2u;
             uint32_t spins = 0;
             while (ld_id(at) != kEmptyId)
                 if (++spins > (1u << 24)) { st1_shared(ctrl + kCtrlAbort, 3u); if (pp.status) atomicOr(pp.status, 4u); break; }
-            st_id(at, id);
+            st_id(at, id | (((pos >> pp.ring_shift) & 15u) << 12));       // the entry carries the lap of its position
         }
     };
     const f3 root_min = ld3(sc.root_min), root_max = ld3(sc.root_max);
@@ -514,14 +544,22 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         const bool active = (uint32_t)lane < n;
         uint32_t id = 0;
         if (active) {
-            const uint32_t at = rings + ((uint32_t)q * pp.ring_cap + ((head + (uint32_t)lane) & ring_mask)) * 2u;
+            // only the entry written for THIS position counts: empty = its producer has reserved the position and not written yet;
+            // another lap's tag = the entry of the position one lap earlier, which its own consumer (a wave that has claimed it and
+            // not got round to reading it) is still to take -- taking that one would put a path in two hands
+            const uint32_t pos = head + (uint32_t)lane;
+            const uint32_t at = rings + ((uint32_t)q * pp.ring_cap + (pos & ring_mask)) * 2u;
+            const uint32_t my_lap = (pos >> pp.ring_shift) & 15u;
             uint32_t spins = 0;
             for (;;) {
-                id = ld_id(at);
-                if (id != kEmptyId) break;
+                const uint32_t e = ld_id(at);
+                id = e & kIdMask;
+                if (e != kEmptyId && (e >> 12) == my_lap) break;
                 if (++spins > (1u << 24)) { st1_shared(ctrl + kCtrlAbort, 2u); if (pp.status) atomicOr(pp.status, 2u); id = 0; break; }
             }
             st_id(at, kEmptyId);
+            // every per-path address below (LDS and the HBM part of the state: aux, aux_slot, aux_light) is formed from this id
+            if (id >= P) { st1_shared(ctrl + kCtrlAbort, 4u); if (pp.status) atomicOr(pp.status, 0x40000u); id = 0; }
         }
         lds_acquire();
         unsigned long long s_t1 = 0;
@@ -624,8 +662,8 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                         float t, u, v;
                         const bool h = tri_intersect_flat(ray, tri[k].v0, tri[k].e1, tri[k].e2, t, u, v) & (first + k < end);
                         if (SUN && shadow) {
-                            if (h && (!ALPHA || any_hit(sc, idx[k], mk3(1.0f - u - v, u, v)))) { occluded = true; cur = end; sp = 0; }
-                        } else if (h && t < hit_t && (!ALPHA || any_hit(sc, idx[k], mk3(1.0f - u - v, u, v)))) { hit_t = t; hit_prim = (uint32_t)idx[k]; }
+                            if (h && (!ALPHA || alpha_test(idx[k], mk3(1.0f - u - v, u, v)))) { occluded = true; cur = end; sp = 0; }
+                        } else if (h && t < hit_t && (!ALPHA || alpha_test(idx[k], mk3(1.0f - u - v, u, v)))) { hit_t = t; hit_prim = (uint32_t)idx[k]; }
                     }
                 }
             }
@@ -640,13 +678,13 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                     const bool h0 = tri_intersect_flat(ray, ta.v0, ta.e1, ta.e2, t0, u0, v0);
                     const bool h1 = tri_intersect_flat(ray, tb.v0, tb.e1, tb.e2, t1, u1, v1) & two;
                     if (SUN && shadow) {                                  // RayTest: any accepted hit ends the traversal (:105-117)
-                        const bool occ = (h0 && (!ALPHA || any_hit(sc, i, mk3(1.0f - u0 - v0, u0, v0)))) ||
-                                         (h1 && (!ALPHA || any_hit(sc, j, mk3(1.0f - u1 - v1, u1, v1))));
+                        const bool occ = (h0 && (!ALPHA || alpha_test(i, mk3(1.0f - u0 - v0, u0, v0)))) ||
+                                         (h1 && (!ALPHA || alpha_test(j, mk3(1.0f - u1 - v1, u1, v1))));
                         if (occ) { occluded = true; cur = end; sp = 0; }
                     } else {
                         // (the barycentrics are not kept: B computes them again for the one triangle that wins)
-                        if (h0 && t0 < hit_t && (!ALPHA || any_hit(sc, i, mk3(1.0f - u0 - v0, u0, v0)))) { hit_t = t0; hit_prim = (uint32_t)i; }
-                        if (h1 && t1 < hit_t && (!ALPHA || any_hit(sc, j, mk3(1.0f - u1 - v1, u1, v1)))) { hit_t = t1; hit_prim = (uint32_t)j; }
+                        if (h0 && t0 < hit_t && (!ALPHA || alpha_test(i, mk3(1.0f - u0 - v0, u0, v0)))) { hit_t = t0; hit_prim = (uint32_t)i; }
+                        if (h1 && t1 < hit_t && (!ALPHA || alpha_test(j, mk3(1.0f - u1 - v1, u1, v1)))) { hit_t = t1; hit_prim = (uint32_t)j; }
                     }
                 }
             }
@@ -701,7 +739,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 const TriCold cold = fetch_cold(hit_prim);                                 // :111-118
                 const MatDev mat = fetch_mat(cold.material);
                 if (mat.tex < 0) throughput = throughput * ld3(mat.albedo);
-                else throughput = throughput * tex_get_pixel(sc, fetch_tex(mat.tex), interp_uv(cold, uvw));
+                else throughput = throughput * tex_get_pixel<true>(sc, fetch_tex(mat.tex), interp_uv(cold, uvw));
                 const f3 origin = position + (normal * 0.001f);                            // :121
                 if (SUN) {
                     // :124-128: the sun's shadow ray starts where the bounce ray will (its origin waits in A), the normal is found
@@ -758,7 +796,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                         light = light + sky_model(mk3(u2f(B.x), u2f(B.y), u2f(B.z)), ld3(fp.sky_color)) * mk3(u2f(E.x), u2f(E.y), u2f(E.z)) * fp.sky_intensity;
                     if (fp.tone_mapping) light = uncharted2_filmic(light, fp.exposure);    // :165-169 (wave-uniform branches)
                     if (fp.gamma_correction) light = gamma_correction(light);
-                    const uint32_t slot_ok = checked(slot, fp.width * fp.local_rows * fp.n_frames, 0x8000u);
+                    const uint32_t slot_ok = held(slot, fp.width * fp.local_rows * fp.n_frames, 0x8000u);
                     if (fp.inline_resolve) accumulate_and_resolve(fp, slot_ok, light);     // one frame in the launch: slot = pixel
                     else samples[slot_ok] = make_float4(light.x, light.y, light.z, 0.0f);
                 }
@@ -910,14 +948,14 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     uint32_t P = 0, ring_cap = 64;
     int groups = 1;
     if (env_paths > 0) {
-        P = std::max<uint32_t>(64u, std::min<uint32_t>((uint32_t)env_paths / 64u * 64u, 4032u));
+        P = std::max<uint32_t>(64u, std::min<uint32_t>((uint32_t)env_paths / 64u * 64u, kMaxPoolPaths));
         while (P > 64u && lds_for(P, ring_cap) > 160u * 1024u) P -= 64u;
         (void)lds_for(P, ring_cap);
     } else {
         uint32_t best_total = 0;
         // (hbm-scene: one pool per CU -- what counts there is resident waves AND spare paths, and one big pool has both)
         for (int g = 1; g <= (hbm_scene ? 1 : 3); g++)
-            for (uint32_t paths = 4032u; paths >= 256u; paths -= 64u) {
+            for (uint32_t paths = kMaxPoolPaths; paths >= 256u; paths -= 64u) {
                 uint32_t cap;
                 if (lds_for(paths, cap) * (uint32_t)g > 160u * 1024u) continue;
                 if (paths * (uint32_t)g >= best_total) { best_total = paths * (uint32_t)g; P = paths; groups = g; }
@@ -951,6 +989,9 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lay.total) != hipSuccess || per_cu < 1) per_cu = 1;
     PoolParams pp;
     pp.P = P; pp.ring_cap = ring_cap; pp.stack_entries = stack_entries;
+    pp.ring_shift = 0;
+    while ((1u << pp.ring_shift) < ring_cap) pp.ring_shift++;
+    if (P > kMaxPoolPaths || (1u << pp.ring_shift) != ring_cap || ring_cap < P) return hipErrorInvalidValue;   // 12-bit ids, power-of-two rings
     pp.total_samples = (uint32_t)(n_chunks * 64ull); pp.n_chunks = (uint32_t)n_chunks; pp.tiles_x = tiles_x;
     pp.t_class[0] = t_class[0]; pp.t_class[1] = t_class[1]; pp.t_class[2] = t_class[2];
     pp.min_fill = (uint32_t)std::max(1, std::min(env_fill, 64)); pp.patience = (uint32_t)std::max(0, env_patience);

@@ -148,3 +148,18 @@ def test_renderer_calls_reject_misuse():
     with pytest.raises(drt.DrtError) as e:
         drt.Renderer(97)
     assert "out of range" in str(e.value)
+
+
+def test_ring_protocol_of_the_pool_kernel_has_no_interleaving_that_puts_a_path_in_two_hands():
+    """kernel_path_pool.hip's queues (multi-producer / multi-consumer rings in LDS): every interleaving of three waves on a
+    ring of two and of four slots is explored.  Round 2's protocol (a consumer takes any non-empty slot) has a schedule in
+    which one path id is taken twice; the lap-tagged entries shipped since round 3 have none (tools/sim_ring_protocol.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sim_ring_protocol", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "sim_ring_protocol.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    hazard, _ = m.explore("r02")
+    assert hazard is not None and "already held" in hazard[-1][1]
+    for kw in (dict(), dict(cap=4, n_ids=3), dict(cap=4, n_ids=4, waves=2, cycles=4)):
+        clean, states = m.explore("lap", **kw)
+        assert clean is None and states > 1000
