@@ -1,6 +1,7 @@
 """Error behaviour of the C ABI (through the Python mirror): every misuse is a status code + message, never a crash or an exit
 (the reference prints and calls exit(99), Editor/Common/CudaCommon.cu:4-13), and nothing falls back to a CPU path."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
