@@ -198,7 +198,8 @@ DRT_DEV bool tri_intersect(const Ray &ray, f3 v0, f3 e1, f3 e2, float &t_out, f3
 DRT_DEV bool tri_intersect_flat(const Ray &ray, f3 v0, f3 e1, f3 e2, float &t, float &u, float &v) {
     f3 pvec = cross(ray.dir, e2);
     float det = dot(e1, pvec);
-    int ok = !((int)(det > -DRT_TRIANGLE_EPSILON) & (int)(det < DRT_TRIANGLE_EPSILON));     // ints: no short-circuit branches
+    // det > -eps && det < eps  <=>  |det| < eps (NaN: false either way): one compare, the absolute value is an operand modifier
+    int ok = !(__builtin_fabsf(det) < DRT_TRIANGLE_EPSILON);
     float inv_det = exact_rcp_not_tiny(det);          // !ok covers |det| < 1e-6: whatever comes back there is not used
     f3 tvec = ray.orig - v0;
     u = inv_det * dot(tvec, pvec);

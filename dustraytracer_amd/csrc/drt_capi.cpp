@@ -95,7 +95,7 @@ struct drt_renderer {
     float span_ms = 0.f;                       // sum of those spans, filled by drt_renderer_wait
     int wall_clock_khz = 100000;
     static constexpr int kCounters = 256;
-    unsigned int *tile_counter = nullptr;     // work queue heads of the tracing kernels: kCounters zeroed words, one per launch, re-zeroed
+    unsigned int *tile_counter = nullptr;     // work queue heads of the tracing kernels: kCounters zeroed blocks (kQueueHeadBlockWords each), one per launch, re-zeroed
     int counters_used = 0;                    // in one memset when all are spent (no memset in front of every launch)
     void *samples = nullptr;                  // wave_queue: one float4 per (pixel, frame) of a launch
     size_t samples_bytes = 0;
@@ -375,8 +375,8 @@ drt_renderer *drt_renderer_create(int32_t device) {
     if (hipEventCreate(&r->ev_start) != hipSuccess || hipEventCreate(&r->ev_stop) != hipSuccess ||
         hipMalloc((void **)&r->counters, sizeof(drt_counters)) != hipSuccess ||
         hipMalloc((void **)&r->spans, sizeof(unsigned long long) * 2 * drt_renderer::kMaxSpans) != hipSuccess ||
-        hipMalloc((void **)&r->tile_counter, sizeof(unsigned int) * drt_renderer::kCounters) != hipSuccess ||
-        hipMemset(r->tile_counter, 0, sizeof(unsigned int) * drt_renderer::kCounters) != hipSuccess ||
+        hipMalloc((void **)&r->tile_counter, sizeof(unsigned int) * drt_renderer::kCounters * kQueueHeadBlockWords) != hipSuccess ||
+        hipMemset(r->tile_counter, 0, sizeof(unsigned int) * drt_renderer::kCounters * kQueueHeadBlockWords) != hipSuccess ||
         hipMalloc((void **)&r->pool_status, sizeof(unsigned int)) != hipSuccess ||
         hipMemset(r->pool_status, 0, sizeof(unsigned int)) != hipSuccess ||
         hipHostMalloc((void **)&r->pool_status_host, sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) {
@@ -694,10 +694,10 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
             fp.span = r->spans_used < drt_renderer::kMaxSpans ? r->spans + 2 * r->spans_used++ : nullptr;
             r->launches_last++;
             if (r->counters_used == drt_renderer::kCounters) {      // stream order: every launch that used them is over by then
-                HIP_TRY(hipMemsetAsync(r->tile_counter, 0, sizeof(unsigned int) * drt_renderer::kCounters, r->stream));
+                HIP_TRY(hipMemsetAsync(r->tile_counter, 0, sizeof(unsigned int) * drt_renderer::kCounters * kQueueHeadBlockWords, r->stream));
                 r->counters_used = 0;
             }
-            unsigned int *const queue_head = r->tile_counter + r->counters_used++;
+            unsigned int *const queue_head = r->tile_counter + (size_t)(r->counters_used++) * kQueueHeadBlockWords;
             bool pool_hbm_scene = false;
             if (r->use_path_pool && !r->counting && !material_ext &&
                 path_pool_supports(r->view, fp, r->bvh_depth, wave_queue_scene_lds_bytes(r->view), &pool_hbm_scene) && (r->pool_launched = true))

@@ -58,6 +58,7 @@ enum : int { QN = 0, QT0 = 1, QB = 5, QE = 6, QR = 7, QS = 8 };
 constexpr uint32_t kEmptyId = 0xFFFFu;                // ring entry: path id | (lap & 15) << 12; ids stop at 4031, so 0xFFFF is never an entry
 constexpr uint32_t kIdMask = 0xFFFu;
 constexpr uint32_t kMaxPoolPaths = 4032u;
+constexpr uint32_t kSampleShards = (uint32_t)kPoolSampleShards, kSampleShardStride = (uint32_t)kPoolSampleShardStride;     // (render_kernels.hpp)
 constexpr uint32_t kNoPrim = 0xFFFu;                 // word W: hit triangle (12 bits, kNoPrim = none) | bounce index << 12 (16 bits) | kHasSample
 constexpr uint32_t kHasSample = 1u << 28;
 constexpr uint32_t kShadow = 1u << 29;               // the traversal under way is the sun's shadow ray (RayTest, BVHTraversal.cuh:76-134)
@@ -140,7 +141,7 @@ __host__ __device__ inline PoolLayout pool_layout(uint32_t P, uint32_t ring_cap,
     l.words = l.quads + 2u * P * 16u;
     l.stack = l.words + P * word_bytes;
     l.scene = (l.stack + stack_entries * P * stack_entry_bytes + 15u) & ~15u;
-    l.cold = l.scene + scene_bytes;
+    l.cold = l.scene + scene_bytes + (scene_bytes ? 48u : 0u);      // (T reads pairs of triangles: the partner of the last one is one record past the end)
     l.total = l.cold + cold_bytes;
     return l;
 }
@@ -273,6 +274,14 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             const uint4 *g = reinterpret_cast<const uint4 *>(sc.tri_hot) + (size_t)i * 3;
             a = g[0]; b = g[1]; c = reinterpret_cast<const uint32_t *>(g)[8];
         } else { a = ld4(q); b = ld4(q + 16); c = ld1(q + 32); }
+        TriTest t;
+        t.v0 = mk3(u2f(a.x), u2f(a.y), u2f(a.z)); t.e1 = mk3(u2f(a.w), u2f(b.x), u2f(b.y)); t.e2 = mk3(u2f(b.z), u2f(b.w), u2f(c));
+        return t;
+    };
+    // (lds-scene build) the triangle at LDS address q; q + 48 bytes past the last triangle is still inside the workgroup's LDS (pool_layout pads)
+    auto fetch_tri_at = [&](uint32_t q) -> TriTest {
+        const uint4 a = ld4(q), b = ld4(q + 16);
+        const uint32_t c = ld1(q + 32);
         TriTest t;
         t.v0 = mk3(u2f(a.x), u2f(a.y), u2f(a.z)); t.e1 = mk3(u2f(a.w), u2f(b.x), u2f(b.y)); t.e2 = mk3(u2f(b.z), u2f(b.w), u2f(c));
         return t;
@@ -414,9 +423,12 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             // all P ids, a path that goes straight back to E lands on exactly such a slot.  Wait for the slot to be empty.
             const uint32_t pos = base + my_rank;
             const uint32_t at = rings + ((uint32_t)dest * pp.ring_cap + (pos & ring_mask)) * 2u;
-            uint32_t spins = 0;
-            while (ld_id(at) != kEmptyId)
-                if (++spins > (1u << 24)) { st1_shared(ctrl + kCtrlAbort, 3u); if (pp.status) atomicOr(pp.status, 4u); break; }
+            if (__builtin_expect(ld_id(at) != kEmptyId, 0)) {             // (rare: kept out of the straight path)
+                uint32_t spins = 0;
+#pragma nounroll
+                while (ld_id(at) != kEmptyId)
+                    if (++spins > (1u << 24)) { st1_shared(ctrl + kCtrlAbort, 3u); if (pp.status) atomicOr(pp.status, 4u); break; }
+            }
             st_id(at, id | (((pos >> pp.ring_shift) & 15u) << 12));       // the entry carries the lap of its position
         }
     };
@@ -467,7 +479,9 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     };
 
     const int wave = tid >> 6;
-    uint32_t polls = 0, idle_polls = 0, rot = (uint32_t)wave;
+    uint32_t polls = 0, idle_polls = 0;
+    uint32_t my_shard = (uint32_t)__builtin_amdgcn_readfirstlane((int)blockIdx.x) & (kSampleShards - 1u);      // scalar: the sample counter this wave draws from
+    uint32_t rot = (uint32_t)__builtin_amdgcn_readfirstlane(wave) % (uint32_t)kNQ;      // scalar: where this wave's round robin over the queues stands
     unsigned long long s_batches[kNQ], s_lanes[kNQ], s_ticks[kNQ], s_claim = 0, s_idle = 0, s_lost = 0, s_fail = 0, s_fail_ticks = 0, s_idle_ticks = 0;
     for (int k = 0; k < kNQ; k++) s_batches[k] = s_lanes[k] = s_ticks[k] = 0;
     const unsigned long long s_t_start = STATS ? __builtin_amdgcn_s_memtime() : 0;
@@ -490,10 +504,10 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         int q = -1, avail = 0;
         const unsigned full_mask = (unsigned)pp_ballot(my_avail >= 64) & ((1u << kNQ) - 1u);
         if (full_mask) {
-            int pick = (int)(rot % (uint32_t)__popc(full_mask));
-            unsigned mm = full_mask;
-            while (pick-- > 0) mm &= mm - 1u;
-            q = __builtin_ctz(mm);
+            // the first queue with a full batch at or after `rot` (scalar arithmetic: rot stays in [0, kNQ))
+            const unsigned turned = ((full_mask >> rot) | (full_mask << ((uint32_t)kNQ - rot))) & ((1u << kNQ) - 1u);
+            const int k = __builtin_ctz(turned) + (int)rot;
+            q = k >= kNQ ? k - kNQ : k;
             avail = 64;
         } else {
 #pragma unroll
@@ -538,7 +552,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             n = (uint32_t)min(left, 64);
         }
         (void)tail_now;
-        ++rot;
+        rot = rot + 1u >= (uint32_t)kNQ ? 0u : rot + 1u;
         if (!won) { if (STATS) { s_fail++; s_fail_ticks += __builtin_amdgcn_s_memtime() - s_t0; } continue; }   // the queue went to other waves: look again
         polls = 0; idle_polls = 0;
         const bool active = (uint32_t)lane < n;
@@ -550,13 +564,17 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             const uint32_t pos = head + (uint32_t)lane;
             const uint32_t at = rings + ((uint32_t)q * pp.ring_cap + (pos & ring_mask)) * 2u;
             const uint32_t my_lap = (pos >> pp.ring_shift) & 15u;
-            uint32_t spins = 0;
-            for (;;) {
-                const uint32_t e = ld_id(at);
-                id = e & kIdMask;
-                if (e != kEmptyId && (e >> 12) == my_lap) break;
-                if (++spins > (1u << 24)) { st1_shared(ctrl + kCtrlAbort, 2u); if (pp.status) atomicOr(pp.status, 2u); id = 0; break; }
+            uint32_t e = ld_id(at);
+            if (__builtin_expect(e == kEmptyId || (e >> 12) != my_lap, 0)) {          // (rare: kept out of the straight path)
+                uint32_t spins = 0;
+#pragma nounroll
+                for (;;) {
+                    e = ld_id(at);
+                    if (e != kEmptyId && (e >> 12) == my_lap) break;
+                    if (++spins > (1u << 24)) { st1_shared(ctrl + kCtrlAbort, 2u); if (pp.status) atomicOr(pp.status, 2u); e = 0; break; }
+                }
             }
+            id = e & kIdMask;
             st_id(at, kEmptyId);
             // every per-path address below (LDS and the HBM part of the state: aux, aux_slot, aux_light) is formed from this id
             if (id >= P) { st1_shared(ctrl + kCtrlAbort, 4u); if (pp.status) atomicOr(pp.status, 0x40000u); id = 0; }
@@ -667,25 +685,33 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                     }
                 }
             }
-            while (!HBM && pp_ballot(cur < end) != 0) {
-                if (cur < end) {
-                    const int i = cur;
-                    const bool two = i + 1 < end;
-                    const int j = two ? i + 1 : i;
-                    cur = j + 1;
-                    const TriTest ta = fetch_tri(i), tb = fetch_tri(j);
+            if (!HBM) {
+                // One LDS address per lane walks the leaf: a pair is at [addr, addr + 96), the second triangle at the constant
+                // offset 48.  A lane whose leaf is used up stays where it is and tests its last pair again, result ignored: no
+                // exec-mask bookkeeping and no loop-carried copies inside the loop (the lanes of a batch are on leaves of one size
+                // class, so they nearly all run to the end together anyway).
+                int left = end - cur;                                     // triangles still to test (<= 0: through)
+                uint32_t addr = lds_hot + __umul24((uint32_t)cur, 48u);
+                for (;;) {
+                    const bool go = left > 0;
+                    if (pp_ballot(go) == 0) break;
+                    const bool two = left > 1;
+                    const TriTest ta = fetch_tri_at(addr), tb = fetch_tri_at(addr + 48u);
                     float t0, u0, v0, t1, u1, v1;
-                    const bool h0 = tri_intersect_flat(ray, ta.v0, ta.e1, ta.e2, t0, u0, v0);
+                    const bool h0 = tri_intersect_flat(ray, ta.v0, ta.e1, ta.e2, t0, u0, v0) & go;
                     const bool h1 = tri_intersect_flat(ray, tb.v0, tb.e1, tb.e2, t1, u1, v1) & two;
+                    const int i = cur, j = cur + 1;
                     if (SUN && shadow) {                                  // RayTest: any accepted hit ends the traversal (:105-117)
                         const bool occ = (h0 && (!ALPHA || alpha_test(i, mk3(1.0f - u0 - v0, u0, v0)))) ||
                                          (h1 && (!ALPHA || alpha_test(j, mk3(1.0f - u1 - v1, u1, v1))));
-                        if (occ) { occluded = true; cur = end; sp = 0; }
+                        if (occ) { occluded = true; left = 0; sp = 0; }
                     } else {
                         // (the barycentrics are not kept: B computes them again for the one triangle that wins)
                         if (h0 && t0 < hit_t && (!ALPHA || alpha_test(i, mk3(1.0f - u0 - v0, u0, v0)))) { hit_t = t0; hit_prim = (uint32_t)i; }
                         if (h1 && t1 < hit_t && (!ALPHA || alpha_test(j, mk3(1.0f - u1 - v1, u1, v1)))) { hit_t = t1; hit_prim = (uint32_t)j; }
                     }
+                    const int step = go ? 2 : 0;
+                    cur += step; left -= step; addr += (uint32_t)step * 48u;
                 }
             }
             if (active) {
@@ -802,17 +828,32 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 }
             }
             // Sample ids.  The first P of a workgroup are fixed (workgroup w starts with [w*P, (w+1)*P): the slots that wait in E's
-            // ring when the kernel starts, positions < P) -- no 8 000 waves hammering one counter while the launch ramps up; after
-            // that one global atomic per batch hands out the ids above gridDim.x * P.
+            // ring when the kernel starts, positions < P) -- no 8 000 waves hammering one counter while the launch ramps up.  The
+            // ids above gridDim.x * P come from kSampleShards counters, each on a cache line of its own: counter k hands out
+            // j = 0, 1, 2, ... and stands for the ids ((j / 64) * kSampleShards + k) * 64 + j % 64 (chunks of 64 dealt round robin
+            // to the counters), one global atomic per batch.  A lone launch on the whole chip makes ~80 M such atomics a second;
+            // on ONE address that rate, not the arithmetic, set its time (three launches in flight, each with its own counter,
+            // ran 22 % faster per frame than one alone).  A wave starts on the counter of its workgroup and moves on when that
+            // one has run dry; a slot retires only after every counter has been found dry.
             const bool initial = active && head + (uint32_t)lane < P;
-            const unsigned long long m = pp_ballot(active && !initial);
-            unsigned int base = 0;
-            if (m != 0) {
-                if (lane == 0) base = atomicAdd(sample_counter, (unsigned int)__popcll(m));
-                base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base) + gridDim.x * P;
+            const uint32_t n_static = gridDim.x * P;
+            const uint32_t n_dynamic = pp.total_samples > n_static ? pp.total_samples - n_static : 0u;
+            uint32_t sid = initial ? blockIdx.x * P + head + (uint32_t)lane : 0xFFFFFFFFu;
+            bool need = active && !initial;
+            for (uint32_t attempt = 0; attempt < kSampleShards; ++attempt) {
+                const unsigned long long m = pp_ballot(need);
+                if (m == 0) break;
+                unsigned int base = 0;
+                if (lane == 0) base = atomicAdd(sample_counter + my_shard * kSampleShardStride, (unsigned int)__popcll(m));
+                base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                if (need) {
+                    const uint32_t j = base + (uint32_t)pp_rank(m);
+                    const uint32_t d = ((((j >> 6) * kSampleShards) + my_shard) << 6) | (j & 63u);
+                    if (d < n_dynamic) { sid = n_static + d; need = false; }
+                }
+                if (pp_ballot(need) != 0) my_shard = (my_shard + 1u) & (kSampleShards - 1u);        // this counter has run dry
             }
             if (active) {
-                const uint32_t sid = initial ? blockIdx.x * P + head + (uint32_t)lane : base + (uint32_t)pp_rank(m);
                 if (sid >= pp.total_samples) {
                     st1_shared(ctrl + kCtrlExhausted, 1u);
                     lds_add(ctrl + kCtrlLive, 0xFFFFFFFFu);                                // this pool slot retires
@@ -920,7 +961,7 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     const int env_threads = tune.threads, env_paths = tune.paths, env_fill = tune.min_fill, env_patience = tune.patience;
     const uint32_t tiles_x = (fp.width + 7) / 8, tiles_y = (fp.local_rows + 7) / 8;
     const uint64_t n_chunks = (uint64_t)tiles_x * tiles_y * fp.n_frames;
-    if (n_chunks * 64ull > 0xFFF00000ull) return hipErrorInvalidValue;
+    if (n_chunks * 64ull > 0xF0000000ull) return hipErrorInvalidValue;       // (room for the ids the sharded counters hand out past the end)
     // Stack slots: the far siblings of the nodes on the way down, one per level below the root -- the near child of a visit stays
     // in registers and is spilled only where it is an interior node, so never more than levels - 1 entries.  (Smaller entries were
     // tried on room, where 64 more paths in the pool are worth 3-5 %: 6 bytes {distance, parent << 1 | which child} cost 3.5 % at
@@ -1027,7 +1068,7 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     }
     pp.aux = static_cast<uint4 *>(scratch.aux); pp.aux_slot = static_cast<uint32_t *>(scratch.aux_slot);
     pp.aux_light = static_cast<float4 *>(scratch.aux_light);
-    hipError_t e = hipSuccess;                 // (*sample_counter is zero: drt_capi.cpp hands out zeroed counters)
+    hipError_t e = hipSuccess;                 // (sample_counter: kPoolSampleShards zeroed counters, kPoolSampleShardStride words apart -- drt_capi.cpp hands out zeroed blocks)
     if (kernel_name) *kernel_name = names[flags >> 1];
     if (launch_shape) { launch_shape[0] = (int)stack_entries; launch_shape[1] = per_cu; launch_shape[2] = (int)(lay.total / 1024); launch_shape[3] = threads; launch_shape[4] = (int)P; }
     FrameParams fq = fp;

@@ -33,6 +33,14 @@ hipError_t launch_wave_queue(const SceneView &scene, const FrameParams &frame, i
 hipError_t launch_resolve(const FrameParams &frame, void *samples, hipStream_t stream);
 size_t wave_queue_scene_lds_bytes(const SceneView &scene);
 
+// The work-queue heads a launch draws from: one block of kPoolSampleShards counters, kPoolSampleShardStride words (128 bytes)
+// apart (path_pool: sample ids sharded over them, so that a whole chip's waves do not serialise on one address; wave_queue
+// uses the first word only).  The renderer hands out zeroed blocks.
+#ifndef DRT_SAMPLE_SHARDS
+#define DRT_SAMPLE_SHARDS 16          // (a power of two; -DDRT_SAMPLE_SHARDS=1 in EXTRA: the single counter of rounds 1-2, for A/B runs)
+#endif
+constexpr int kPoolSampleShards = DRT_SAMPLE_SHARDS, kPoolSampleShardStride = 32, kQueueHeadBlockWords = kPoolSampleShards * kPoolSampleShardStride;
+
 // path_pool (kernel_path_pool.hip): path state parked in LDS, phase-homogeneous batches of 64 paths; lean paths of scenes
 // whose traversal data fits LDS.  `status` is a device word the kernel sets when it had to abort (never hangs).
 bool path_pool_supports(const SceneView &scene, const FrameParams &frame, int bvh_depth, size_t scene_lds_bytes, bool *hbm_scene);
