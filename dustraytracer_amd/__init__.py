@@ -581,6 +581,7 @@ class Renderer:
             out[name] = (b, l / max(b, 1), t)
         out["claim_ticks"], out["idle_polls"], out["lost_claims"], out["wave_ticks"] = int(a[27]), int(a[28]), int(a[29]), int(a[30])
         out["failed_claims"], out["failed_claim_ticks"], out["idle_ticks"] = int(a[31]), int(a[32]), int(a[33])
+        out["work"] = dict(n_iterations=int(a[34]), n_lane_pops=int(a[35]), t_steps=int(a[36]), t_lane_tests=int(a[37]), dir_iterations=int(a[38]), dir_lane_tries=int(a[39]))
         return out
 
     def launchesOfLastBatch(self):

@@ -363,6 +363,8 @@ drt_renderer *drt_renderer_create(int32_t device) {
     r->pool_tuning.patience = env_int("DRT_POOL_PATIENCE", r->pool_tuning.patience);
     r->pool_tuning.n_loop = env_int("DRT_POOL_N_LOOP", r->pool_tuning.n_loop);
     r->pool_tuning.n_min_lanes = env_int("DRT_POOL_N_MIN", r->pool_tuning.n_min_lanes);
+    r->pool_tuning.n_fuse_loop = env_int("DRT_POOL_N_FUSE_LOOP", r->pool_tuning.n_fuse_loop);
+    r->pool_tuning.n_fuse_min = env_int("DRT_POOL_N_FUSE_MIN", r->pool_tuning.n_fuse_min);
     r->pool_tuning.cold_lds_kb = env_int("DRT_POOL_COLD_KB", r->pool_tuning.cold_lds_kb);
     r->pool_tuning.share_grid = env_int("DRT_POOL_SHARE_GRID", r->pool_tuning.share_grid);
     r->pool_tuning.dir_tries = env_int("DRT_POOL_DIR_TRIES", r->pool_tuning.dir_tries);

@@ -162,6 +162,8 @@ struct PoolParams {
     uint32_t patience;         // ... for this many polls
     uint32_t n_loop;           // N: at most this many pops per batch ...
     uint32_t n_min_lanes;      // ... and the batch ends when fewer lanes than this are still popping (the rest go back to N)
+    uint32_t n_fuse_loop;      // a batch that launches rays (B / S / R / E): at most this many visits per new ray, the root's included ...
+    uint32_t n_fuse_min;       // ... and only while at least this many lanes still need one
     uint32_t cold_in_lds;      // TriCold / MatDev / TexDev records staged in LDS too (small scenes): B's loads chain through LDS
     uint32_t dir_tries;        // B and R draw at most this many candidates of the bounce direction per batch; paths still without one go (back) to R
     uint4 *aux;                // HBM, [workgroup][path]: {throughput, seed} -- what only B and E touch stays out of LDS
@@ -175,62 +177,86 @@ struct PoolParams {
 // 8 = hbm-scene: the traversal data is too big for LDS and is read from global memory (L2); the pool -- path state, stacks, queues --
 // is the same, with 32-bit triangle indices: word W becomes a quad {meta = bounce | stack height << 16 | flags, hit triangle, leaf end, -}
 // and B's fourth word the current triangle
+// The arguments travel as ONE struct, and the kernel never names it: every field is read from the kernarg segment where it is
+// used, through a pointer that is made opaque at the top of every batch (`ka`, below).  Named by-value arguments are loaded at
+// the kernel's entry and stay live across the whole loop -- ~130 dwords of them, which the register allocator then spills to
+// VGPR lanes and reloads inside the claim, push and traversal code (85 SGPR spills in round 2); read where they are used, the
+// camera, sky and frame constants occupy registers only inside the phase that needs them.
+struct PoolArgs { SceneView sc; FrameParams fp; PoolParams pp; unsigned int *sample_counter; float4 *samples; };
 template <int FLAGS>
-__global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneView sc, const FrameParams fp, const PoolParams pp,
-                                                                    unsigned int *sample_counter, float4 *samples) {
+__global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolArgs) {
+    // the kernel arguments, read from the kernarg segment (scalar loads) at the point of use
+    typedef const PoolArgs __attribute__((address_space(4))) *KernArgs;
+    KernArgs ka = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    auto SC = [&]() -> const SceneView & { return *(const SceneView *)&ka->sc; };
+    auto FP = [&]() -> const FrameParams & { return *(const FrameParams *)&ka->fp; };
+    auto PA = [&]() -> const PoolParams & { return *(const PoolParams *)&ka->pp; };
+
     constexpr bool STATS = (FLAGS & 1) != 0, SUN = (FLAGS & 2) != 0, ALPHA = (FLAGS & 4) != 0, HBM = (FLAGS & 8) != 0;
     constexpr uint32_t kWordBytes = HBM ? 16u : 4u, kStackEntryBytes = HBM ? 6u : 8u;
     extern __shared__ uint4 lds_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const uint32_t wg = blockDim.x;
-    const uint32_t P = pp.P;
-    const uint32_t ring_mask = pp.ring_cap - 1u;
-    const bool cold_lds = pp.cold_in_lds != 0;
+    const uint32_t P = PA().P;
+    // (the parameters the hot phases use stay in scalar registers for the whole launch; everything else is read where it is used)
+    const uint32_t k_ring_cap = PA().ring_cap;
+    const uint32_t k_ring_shift = PA().ring_shift;
+    const uint32_t k_min_fill = PA().min_fill;
+    const uint32_t k_patience = PA().patience;
+    const uint32_t k_n_loop = PA().n_loop;
+    const uint32_t k_n_min_lanes = PA().n_min_lanes;
+    const uint32_t k_n_fuse_loop = PA().n_fuse_loop;
+    const uint32_t k_n_fuse_min = PA().n_fuse_min;
+    const uint32_t k_dir_tries = PA().dir_tries;
+    const uint32_t k_stack_entries = PA().stack_entries;
+    const uint32_t k_t_class0 = PA().t_class[0], k_t_class1 = PA().t_class[1], k_t_class2 = PA().t_class[2];
+    const uint32_t ring_mask = k_ring_cap - 1u;
+    const bool cold_lds = PA().cold_in_lds != 0;
     constexpr uint32_t kRings = SUN ? (uint32_t)kNQ : (uint32_t)kNQ - 1u;
-    const PoolLayout lay = pool_layout(P, pp.ring_cap, pp.stack_entries, HBM ? 0u : pool_scene_bytes(sc), cold_lds ? pool_cold_bytes(sc) : 0u, kRings, kWordBytes, kStackEntryBytes);
+    const PoolLayout lay = pool_layout(P, k_ring_cap, k_stack_entries, HBM ? 0u : pool_scene_bytes(SC()), cold_lds ? pool_cold_bytes(SC()) : 0u, kRings, kWordBytes, kStackEntryBytes);
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds_raw);      // low 32 bits of the flat address = LDS offset
     const uint32_t ctrl = lds_base + lay.ctrl, rings = lds_base + lay.rings, stack = lds_base + lay.stack;
     const uint32_t qA = lds_base + lay.quads, qB = qA + P * 16u, qW = lds_base + lay.words;
-    const uint32_t lds_inner = lds_base + lay.scene, lds_hot = lds_inner + sc.n_inner * 64u;
-    const uint32_t lds_cold = lds_base + lay.cold, lds_mats = lds_cold + sc.n_tris * 32u, lds_texs = lds_mats + sc.n_mats * 16u;
-    uint4 *const aux = pp.aux + (size_t)blockIdx.x * P;
-    uint32_t *const aux_slot = pp.aux_slot + (size_t)blockIdx.x * P;
-    float4 *const aux_light = pp.aux_light + (size_t)blockIdx.x * P;
+    const uint32_t lds_inner = lds_base + lay.scene, lds_hot = lds_inner + SC().n_inner * 64u;
+    const uint32_t lds_cold = lds_base + lay.cold, lds_mats = lds_cold + SC().n_tris * 32u, lds_texs = lds_mats + SC().n_mats * 16u;
+    uint4 *const aux = PA().aux + (size_t)blockIdx.x * P;
+    uint32_t *const aux_slot = PA().aux_slot + (size_t)blockIdx.x * P;
+    float4 *const aux_light = PA().aux_light + (size_t)blockIdx.x * P;
 
-    if (fp.span && lane == 0) atomicMax(&fp.span[0], ~(unsigned long long)wall_clock64());
+    if (FP().span && lane == 0) atomicMax(&FP().span[0], ~(unsigned long long)wall_clock64());
 
     // ---- prologue: scene copy, empty rings, every pool slot waits in E without a sample ----
     {
-        const uint4 *g_inner = reinterpret_cast<const uint4 *>(sc.inner);
-        const uint4 *g_hot = reinterpret_cast<const uint4 *>(sc.tri_hot);
+        const uint4 *g_inner = reinterpret_cast<const uint4 *>(SC().inner);
+        const uint4 *g_hot = reinterpret_cast<const uint4 *>(SC().tri_hot);
         // (leaf references are rewritten while the records are staged: kLeafBit | count << 12 | first triangle -- reaching a leaf
         // then costs no LeafRange load; n_tris < 4096 is what path_pool_supports guarantees)
-        for (uint32_t i = tid; !HBM && i < sc.n_inner * 4u; i += wg) {
+        for (uint32_t i = tid; !HBM && i < SC().n_inner * 4u; i += wg) {
             uint4 v = g_inner[i];
             if ((i & 3u) == 3u) {
-                if (v.x & kLeafBit) { const LeafRange lr = sc.leaves[v.x & ~kLeafBit]; v.x = kLeafBit | ((uint32_t)lr.count << 12) | (uint32_t)lr.start; }
-                if (v.y & kLeafBit) { const LeafRange lr = sc.leaves[v.y & ~kLeafBit]; v.y = kLeafBit | ((uint32_t)lr.count << 12) | (uint32_t)lr.start; }
+                if (v.x & kLeafBit) { const LeafRange lr = SC().leaves[v.x & ~kLeafBit]; v.x = kLeafBit | ((uint32_t)lr.count << 12) | (uint32_t)lr.start; }
+                if (v.y & kLeafBit) { const LeafRange lr = SC().leaves[v.y & ~kLeafBit]; v.y = kLeafBit | ((uint32_t)lr.count << 12) | (uint32_t)lr.start; }
             }
             st4(lds_inner + i * 16u, v);
         }
-        for (uint32_t i = tid; !HBM && i < sc.n_tris * 3u; i += wg) st4(lds_hot + i * 16u, g_hot[i]);
+        for (uint32_t i = tid; !HBM && i < SC().n_tris * 3u; i += wg) st4(lds_hot + i * 16u, g_hot[i]);
         if (cold_lds) {
-            const uint4 *g_cold = reinterpret_cast<const uint4 *>(sc.tri_cold);
-            const uint4 *g_mats = reinterpret_cast<const uint4 *>(sc.mats);
-            const uint4 *g_texs = reinterpret_cast<const uint4 *>(sc.texs);
-            for (uint32_t i = tid; i < sc.n_tris * 2u; i += wg) st4(lds_cold + i * 16u, g_cold[i]);
-            for (uint32_t i = tid; i < sc.n_mats; i += wg) st4(lds_mats + i * 16u, g_mats[i]);
-            for (uint32_t i = tid; i < sc.n_texs; i += wg) st4(lds_texs + i * 16u, g_texs[i]);
+            const uint4 *g_cold = reinterpret_cast<const uint4 *>(SC().tri_cold);
+            const uint4 *g_mats = reinterpret_cast<const uint4 *>(SC().mats);
+            const uint4 *g_texs = reinterpret_cast<const uint4 *>(SC().texs);
+            for (uint32_t i = tid; i < SC().n_tris * 2u; i += wg) st4(lds_cold + i * 16u, g_cold[i]);
+            for (uint32_t i = tid; i < SC().n_mats; i += wg) st4(lds_mats + i * 16u, g_mats[i]);
+            for (uint32_t i = tid; i < SC().n_texs; i += wg) st4(lds_texs + i * 16u, g_texs[i]);
         }
-        for (uint32_t i = tid; i < kRings * pp.ring_cap; i += wg) st_id(rings + i * 2u, kEmptyId);
+        for (uint32_t i = tid; i < kRings * k_ring_cap; i += wg) st_id(rings + i * 2u, kEmptyId);
         for (uint32_t i = tid; i < 32u; i += wg) st1(ctrl + i * 4u, 0u);
         for (uint32_t i = tid; i < P; i += wg) {                                                  // no sample yet
             if (HBM) st4(qW + i * 16u, make_uint4(0u, 0u, 0u, 0u));                                // {meta, hit triangle, leaf end, -}: all of it
             else st1(qW + i * 4u, kNoPrim);
         }
         __syncthreads();
-        for (uint32_t i = tid; i < P; i += wg) st_id(rings + ((uint32_t)QE * pp.ring_cap + i) * 2u, i);
+        for (uint32_t i = tid; i < P; i += wg) st_id(rings + ((uint32_t)QE * k_ring_cap + i) * 2u, i);
         if (tid == 0) { st1(ctrl + QE * 8u + 4u, P); st1(ctrl + kCtrlLive, P); }
         __syncthreads();
     }
@@ -271,7 +297,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         const uint32_t q = lds_hot + __umul24((uint32_t)i, 48u);
         uint4 a, b; uint32_t c;
         if (HBM) {                                   // (i: range-checked by the caller, once per batch)
-            const uint4 *g = reinterpret_cast<const uint4 *>(sc.tri_hot) + (size_t)i * 3;
+            const uint4 *g = reinterpret_cast<const uint4 *>(SC().tri_hot) + (size_t)i * 3;
             a = g[0]; b = g[1]; c = reinterpret_cast<const uint32_t *>(g)[8];
         } else { a = ld4(q); b = ld4(q + 16); c = ld1(q + 32); }
         TriTest t;
@@ -290,8 +316,8 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         const uint32_t q = lds_inner + index * 64u;
         uint4 a, b, c; uint2 r;
         if (HBM) {
-            index = checked(index, sc.n_inner, 0x200u);
-            const uint4 *g = reinterpret_cast<const uint4 *>(sc.inner) + (size_t)index * 4;
+            index = checked(index, SC().n_inner, 0x200u);
+            const uint4 *g = reinterpret_cast<const uint4 *>(SC().inner) + (size_t)index * 4;
             a = g[0]; b = g[1]; c = g[2]; r = *reinterpret_cast<const uint2 *>(g + 3);
         } else { a = ld4(q); b = ld4(q + 16); c = ld4(q + 32); r = ld2(q + 48); }
         ChildPair p;
@@ -301,12 +327,12 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         return p;
     };
     auto fetch_face_normal = [&](int prim) -> f3 {
-        if (HBM) return ld3(sc.tri_hot[prim].fn);    // (prim: range-checked by the caller)
+        if (HBM) return ld3(SC().tri_hot[prim].fn);    // (prim: range-checked by the caller)
         const uint32_t q = lds_hot + __umul24((uint32_t)prim, 48u) + 36u;
         return mk3(u2f(ld1(q)), u2f(ld1(q + 4)), u2f(ld1(q + 8)));
     };
     auto fetch_cold = [&](int prim) -> TriCold {
-        if (!cold_lds) return sc.tri_cold[held((uint32_t)prim, sc.n_tris, 0x80000u)];
+        if (!cold_lds) return SC().tri_cold[held((uint32_t)prim, SC().n_tris, 0x80000u)];
         const uint32_t q = lds_cold + (uint32_t)prim * 32u;
         const uint4 a = ld4(q), b = ld4(q + 16);
         TriCold c;
@@ -315,13 +341,13 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         return c;
     };
     auto fetch_mat = [&](int index) -> MatDev {
-        if (!cold_lds) return sc.mats[held((uint32_t)index, sc.n_mats, 0x2000u)];
+        if (!cold_lds) return SC().mats[held((uint32_t)index, SC().n_mats, 0x2000u)];
         const uint4 a = ld4(lds_mats + (uint32_t)index * 16u);
         MatDev m; m.albedo[0] = u2f(a.x); m.albedo[1] = u2f(a.y); m.albedo[2] = u2f(a.z); m.tex = (int32_t)a.w;
         return m;
     };
     auto fetch_tex = [&](int index) -> TexDev {
-        if (!cold_lds) return sc.texs[held((uint32_t)index, sc.n_texs, 0x4000u)];
+        if (!cold_lds) return SC().texs[held((uint32_t)index, SC().n_texs, 0x4000u)];
         const uint4 a = ld4(lds_texs + (uint32_t)index * 16u);
         TexDev t; t.width = (int32_t)a.x; t.height = (int32_t)a.y; t.comps = (int32_t)a.z; t.offset = a.w;
         return t;
@@ -335,18 +361,18 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         if (mat.tex < 0) return true;
         const TexDev tex = fetch_tex(mat.tex);
         if (tex.comps < 4) return true;
-        const float alpha = tex_get_alpha<true>(sc, tex, interp_uv(cold, uvw));
+        const float alpha = tex_get_alpha<true>(SC(), tex, interp_uv(cold, uvw));
         return !(alpha < 1);
     };
     // leaf -> its triangles [cur, end) and the T queue of its size class.  leaf_ref: count << 12 | first triangle in the lds-scene
     // build (the staged records carry it), the leaf's index in the hbm-scene build
     auto leaf_state = [&](uint32_t leaf_ref, uint32_t &cur, uint32_t &end) -> int {
         uint32_t count;
-        if (HBM) { const LeafRange lr = sc.leaves[checked(leaf_ref, sc.n_leaves, 0x400u)]; cur = (uint32_t)lr.start; count = (uint32_t)lr.count; }
+        if (HBM) { const LeafRange lr = SC().leaves[checked(leaf_ref, SC().n_leaves, 0x400u)]; cur = (uint32_t)lr.start; count = (uint32_t)lr.count; }
         else { cur = leaf_ref & 0xFFFu; count = leaf_ref >> 12; }
         end = cur + count;
         const uint32_t steps = (count + 1u) >> 1;
-        return QT0 + (steps <= pp.t_class[0] ? 0 : (steps <= pp.t_class[1] ? 1 : (steps <= pp.t_class[2] ? 2 : 3)));
+        return QT0 + (steps <= k_t_class0 ? 0 : (steps <= k_t_class1 ? 1 : (steps <= k_t_class2 ? 2 : 3)));
     };
     // traversal over: a path with a hit is shaded (B), one without ends on the sky (E)
     // (a shadow traversal: on to S, the second half of the shading)
@@ -354,15 +380,15 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
     // Stack entries {node reference, slab distance}, [level][path]: 8 bytes in the lds-scene build; the hbm-scene build, whose deep trees
     // make the stacks most of a path's LDS, keeps the distances in one array and 16-bit references (bit 15 = leaf) in another:
     // 6 bytes, a quarter more paths per CU (path_pool_supports: fewer than 32768 interior nodes and leaves)
-    const uint32_t stack_refs = stack + pp.stack_entries * P * 4u;
+    const uint32_t stack_refs = stack + k_stack_entries * P * 4u;
     auto stack_load = [&](int level, uint32_t id) -> uint2 {
-        const uint32_t at = (STATS ? checked((uint32_t)level, pp.stack_entries, 0x10000u) : (uint32_t)level) * P + id;   // (LDS: cannot fault)
+        const uint32_t at = (STATS ? checked((uint32_t)level, k_stack_entries, 0x10000u) : (uint32_t)level) * P + id;   // (LDS: cannot fault)
         if (!HBM) return ld2(stack + at * 8u);
         const uint32_t r16 = ld_u16(stack_refs + at * 2u);
         return make_uint2((r16 & 0x8000u) ? (kLeafBit | (r16 & 0x7FFFu)) : r16, ld1(stack + at * 4u));
     };
     auto stack_store = [&](int level, uint32_t id, uint2 e) {
-        const uint32_t at = (STATS ? checked((uint32_t)level, pp.stack_entries, 0x20000u) : (uint32_t)level) * P + id;
+        const uint32_t at = (STATS ? checked((uint32_t)level, k_stack_entries, 0x20000u) : (uint32_t)level) * P + id;
         if (!HBM) { st2(stack + at * 8u, e); return; }
         st_u16(stack_refs + at * 2u, (e.x & kLeafBit) ? (0x8000u | (e.x & 0x7FFFu)) : e.x);
         st1(stack + at * 4u, e.y);
@@ -422,71 +448,70 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             // outstanding, so the head is past it) but may not have read and cleared it yet -- at the start, when E's ring holds
             // all P ids, a path that goes straight back to E lands on exactly such a slot.  Wait for the slot to be empty.
             const uint32_t pos = base + my_rank;
-            const uint32_t at = rings + ((uint32_t)dest * pp.ring_cap + (pos & ring_mask)) * 2u;
+            const uint32_t at = rings + ((uint32_t)dest * k_ring_cap + (pos & ring_mask)) * 2u;
             if (__builtin_expect(ld_id(at) != kEmptyId, 0)) {             // (rare: kept out of the straight path)
                 uint32_t spins = 0;
 #pragma nounroll
                 while (ld_id(at) != kEmptyId)
-                    if (++spins > (1u << 24)) { st1_shared(ctrl + kCtrlAbort, 3u); if (pp.status) atomicOr(pp.status, 4u); break; }
+                    if (++spins > (1u << 24)) { st1_shared(ctrl + kCtrlAbort, 3u); if (PA().status) atomicOr(PA().status, 4u); break; }
             }
-            st_id(at, id | (((pos >> pp.ring_shift) & 15u) << 12));       // the entry carries the lap of its position
+            st_id(at, id | (((pos >> k_ring_shift) & 15u) << 12));       // the entry carries the lap of its position
         }
     };
-    const f3 root_min = ld3(sc.root_min), root_max = ld3(sc.root_max);
+    const f3 root_min = ld3(SC().root_min), root_max = ld3(SC().root_max);
     // TraceRay.cu:15-20 + BVHTraversal.cuh:22-26,38: the root goes on the stack with its slab distance when -1 < d < FLT_MAX
-    uint32_t root_ref = sc.root_ref;                      // (a one-leaf scene: the same self-describing form as the staged records)
-    if (!HBM && root_ref != kNoNode && (root_ref & kLeafBit)) { const LeafRange lr = sc.leaves[root_ref & ~kLeafBit]; root_ref = kLeafBit | ((uint32_t)lr.count << 12) | (uint32_t)lr.start; }
+    uint32_t root_ref = SC().root_ref;                      // (a one-leaf scene: the same self-describing form as the staged records)
+    if (!HBM && root_ref != kNoNode && (root_ref & kLeafBit)) { const LeafRange lr = SC().leaves[root_ref & ~kLeafBit]; root_ref = kLeafBit | ((uint32_t)lr.count << 12) | (uint32_t)lr.start; }
     auto begin_closest = [&](const Ray &ray, uint2 &top) -> bool {
-        if (sc.root_ref == kNoNode) return false;
+        if (SC().root_ref == kNoNode) return false;
         const float d = slab_intersect(root_min, root_max, ray);
         if (!(-1.0f < d && d < FLT_MAX)) return false;
         top = make_uint2(root_ref, f2u(d));
         return true;
     };
-    // A new ray: the root's entry (`top`, when have_top) is visited right away (every lane of the batch needs that), the state is
-    // stored.  Returns the queue the path goes to.
-    auto launch_with = [&](uint32_t id, const Ray &ray, uint32_t w_word, uint2 top, bool have_top, bool shadow) -> int {
-        int sp = 0;
-        uint32_t cur = 0, end = 0;
-        int dest = -1;
-        if (have_top) dest = pop_step(ray, FLT_MAX, sp, id, cur, end, top, have_top);   // the root's visit
-        if (dest < 0) {
-            spill_top(sp, id, top, have_top);
-            cur = end = 0;
-            dest = sp > 0 ? QN : after_traversal(FLT_MAX, shadow);                       // nothing to traverse: sky (E) / not occluded (S)
-        }
-        // hit distance FLT_MAX: for a shadow ray it stays there, so that N's culls (:41, :63-70) never apply -- RayTest has none
-        st4(qA + id * 16u, make_uint4(f2u(ray.orig.x), f2u(ray.orig.y), f2u(ray.orig.z), f2u(FLT_MAX)));
-        if (HBM) {
-            st4(qB + id * 16u, make_uint4(f2u(ray.dir.x), f2u(ray.dir.y), f2u(ray.dir.z), cur));
-            st1(meta_at(id), w_word | ((uint32_t)sp << 16));
-            st1(meta_at(id) + 8u, end);
-        } else {
-            st4(qB + id * 16u, make_uint4(f2u(ray.dir.x), f2u(ray.dir.y), f2u(ray.dir.z), cur | (end << 12) | ((uint32_t)sp << 24)));
-            st1(meta_at(id), w_word);
-        }
-        return dest;
+    // Traversal registers of a lane: what the N loop works on.  A lane gets them either from LDS (an N batch: a path whose
+    // traversal is under way) or from a launch (B / S / R / E start a new ray: the root's entry is its first visit) -- the
+    // launching batch then runs the N loop itself, so that a new ray's first pops cost no trip through the N queue.
+    struct Trav {
+        Ray ray; float hit_t; int sp; uint32_t cur, end, meta; uint2 top; bool have_top, shadow;
+        bool on;            // takes part in the N loop of this batch
+        bool fresh;         // launched by this batch: its whole state is stored afterwards, not just the traversal part
+        uint32_t hit_store; // fresh: the hit distance written to LDS (FLT_MAX; 0 for a path that never traces, RayGen.cuh:88)
     };
-    auto launch_ray = [&](uint32_t id, const Ray &ray, uint32_t bounce, bool trace) -> int {
+    auto trav_idle = [&]() -> Trav {
+        Trav t; t.ray = make_ray(mk3(0, 0, 0), mk3(0, 0, 1)); t.hit_t = FLT_MAX; t.sp = 0; t.cur = t.end = t.meta = 0; t.top = make_uint2(0u, 0u);
+        t.have_top = t.shadow = t.on = t.fresh = false; t.hit_store = f2u(FLT_MAX);
+        return t;
+    };
+    // A new ray (TraceRay.cu:15-20): hit distance FLT_MAX -- for a shadow ray it stays there, so that N's culls
+    // (BVHTraversal.cuh:41, :63-70) never apply: RayTest has none
+    auto launch_with = [&](Trav &t, const Ray &ray, uint32_t w_word, uint2 top, bool have_top, bool shadow) {
+        t.ray = ray; t.hit_t = FLT_MAX; t.sp = 0; t.cur = t.end = 0; t.meta = w_word; t.top = top; t.have_top = have_top; t.shadow = shadow;
+        t.on = have_top; t.fresh = true; t.hit_store = f2u(FLT_MAX);
+    };
+    auto launch_ray = [&](Trav &t, const Ray &ray, uint32_t bounce, bool trace) {
         uint2 top = make_uint2(0u, 0u);
         const bool have_top = trace && begin_closest(ray, top);
-        return launch_with(id, ray, make_meta(kNoPrim, bounce, kHasSample), top, have_top, false);
+        launch_with(t, ray, make_meta(kNoPrim, bounce, kHasSample), top, have_top, false);
+        if (!trace) t.hit_store = 0u;                 // RayGen.cuh:88: the loop body never runs, the sample is black (E adds no sky light)
     };
     // RayTest (BVHTraversal.cuh:76-134): the root is visited unless its slab test says "behind" (:95-103), no distance culls
-    auto launch_shadow = [&](uint32_t id, const Ray &ray, uint32_t w_word) -> int {
-        const bool have_top = sc.root_ref != kNoNode && !(slab_intersect(root_min, root_max, ray) < 0);
-        return launch_with(id, ray, w_word, make_uint2(root_ref, f2u(0.0f)), have_top, true);
+    auto launch_shadow = [&](Trav &t, const Ray &ray, uint32_t w_word) {
+        const bool have_top = SC().root_ref != kNoNode && !(slab_intersect(root_min, root_max, ray) < 0);
+        launch_with(t, ray, w_word, make_uint2(root_ref, f2u(0.0f)), have_top, true);
     };
 
     const int wave = tid >> 6;
     uint32_t polls = 0, idle_polls = 0;
     uint32_t my_shard = (uint32_t)__builtin_amdgcn_readfirstlane((int)blockIdx.x) & (kSampleShards - 1u);      // scalar: the sample counter this wave draws from
     uint32_t rot = (uint32_t)__builtin_amdgcn_readfirstlane(wave) % (uint32_t)kNQ;      // scalar: where this wave's round robin over the queues stands
+    unsigned long long s_work[6] = { 0, 0, 0, 0, 0, 0 };      // STATS: N iterations / lane pops, T steps / lane steps, direction-try iterations / lane tries
     unsigned long long s_batches[kNQ], s_lanes[kNQ], s_ticks[kNQ], s_claim = 0, s_idle = 0, s_lost = 0, s_fail = 0, s_fail_ticks = 0, s_idle_ticks = 0;
     for (int k = 0; k < kNQ; k++) s_batches[k] = s_lanes[k] = s_ticks[k] = 0;
     const unsigned long long s_t_start = STATS ? __builtin_amdgcn_s_memtime() : 0;
     unsigned long long s_t0 = s_t_start;
     for (;;) {
+        asm volatile("" : "+s"(ka));        // a fresh view of the arguments: nothing read through it is carried over from the batch before
         if (STATS) s_t0 = __builtin_amdgcn_s_memtime();
         // (lds-scene build: a wave that is claiming or pushing goes ahead of the waves inside a phase -- these are short chains of LDS
         // round trips, and the sooner they are through the sooner 64 more lanes have work: room -2 %, cornell -1 %; the hbm-scene
@@ -521,10 +546,10 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             if (live == 0) break;                                         // every pool slot retired: the launch is done
             __builtin_amdgcn_s_sleep(8);
             if (STATS) { s_idle++; s_idle_ticks += __builtin_amdgcn_s_memtime() - s_t0; }
-            if (++idle_polls > (1u << 22)) { st1_shared(ctrl + kCtrlAbort, 1u); if (lane == 0 && pp.status) atomicOr(pp.status, 1u); break; }
+            if (++idle_polls > (1u << 22)) { st1_shared(ctrl + kCtrlAbort, 1u); if (lane == 0 && PA().status) atomicOr(PA().status, 1u); break; }
             continue;
         }
-        if ((uint32_t)avail < pp.min_fill && polls < pp.patience && exhausted == 0) {
+        if ((uint32_t)avail < k_min_fill && polls < k_patience && exhausted == 0) {
             ++polls;
             __builtin_amdgcn_s_sleep(2);
             if (STATS) { s_idle++; s_idle_ticks += __builtin_amdgcn_s_memtime() - s_t0; }
@@ -547,7 +572,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             head = (uint32_t)__builtin_amdgcn_readfirstlane((int)ht.x);
             tail_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)ht.y);
             const int left = (int)(tail_now - head);
-            if (left < (int)pp.min_fill && exhausted == 0) break;
+            if (left < (int)k_min_fill && exhausted == 0) break;
             if (left <= 0) break;
             n = (uint32_t)min(left, 64);
         }
@@ -562,8 +587,8 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             // another lap's tag = the entry of the position one lap earlier, which its own consumer (a wave that has claimed it and
             // not got round to reading it) is still to take -- taking that one would put a path in two hands
             const uint32_t pos = head + (uint32_t)lane;
-            const uint32_t at = rings + ((uint32_t)q * pp.ring_cap + (pos & ring_mask)) * 2u;
-            const uint32_t my_lap = (pos >> pp.ring_shift) & 15u;
+            const uint32_t at = rings + ((uint32_t)q * k_ring_cap + (pos & ring_mask)) * 2u;
+            const uint32_t my_lap = (pos >> k_ring_shift) & 15u;
             uint32_t e = ld_id(at);
             if (__builtin_expect(e == kEmptyId || (e >> 12) != my_lap, 0)) {          // (rare: kept out of the straight path)
                 uint32_t spins = 0;
@@ -571,21 +596,22 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 for (;;) {
                     e = ld_id(at);
                     if (e != kEmptyId && (e >> 12) == my_lap) break;
-                    if (++spins > (1u << 24)) { st1_shared(ctrl + kCtrlAbort, 2u); if (pp.status) atomicOr(pp.status, 2u); e = 0; break; }
+                    if (++spins > (1u << 24)) { st1_shared(ctrl + kCtrlAbort, 2u); if (PA().status) atomicOr(PA().status, 2u); e = 0; break; }
                 }
             }
             id = e & kIdMask;
             st_id(at, kEmptyId);
             // every per-path address below (LDS and the HBM part of the state: aux, aux_slot, aux_light) is formed from this id
-            if (id >= P) { st1_shared(ctrl + kCtrlAbort, 4u); if (pp.status) atomicOr(pp.status, 0x40000u); id = 0; }
+            if (id >= P) { st1_shared(ctrl + kCtrlAbort, 4u); if (PA().status) atomicOr(PA().status, 0x40000u); id = 0; }
         }
         lds_acquire();
         unsigned long long s_t1 = 0;
         if (STATS) { s_t1 = __builtin_amdgcn_s_memtime(); s_claim += s_t1 - s_t0; s_batches[q]++; s_lanes[q] += n; }
         if (!HBM) __builtin_amdgcn_s_setprio(0);
         int dest = -1;                                                    // queue this lane's path goes to next
+        Trav tr = trav_idle();                                            // this lane's traversal registers (an N batch loads them, a launch sets them)
         // bounce direction being drawn (B, R): randomUnitSphereVec3 is a rejection loop (Random.cu:50-58, ~2.9 candidates on
-        // average, a long tail); a batch draws at most pp.dir_tries candidates per path with every lane that still needs one,
+        // average, a long tail); a batch draws at most k_dir_tries candidates per path with every lane that still needs one,
         // then launches the rays that have their direction and sends the others to R with their RNG state
         bool need_dir = false;
         f3 dir_origin = mk3(0, 0, 0), dir_normal = mk3(0, 0, 0), dir_thr = mk3(1, 1, 1);
@@ -593,9 +619,10 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
         auto draw_and_launch = [&](bool store_throughput) {
             f3 p = mk3(0, 0, 0);
             bool have = false;
-            for (uint32_t k = 0; k < pp.dir_tries; k++) {
+            for (uint32_t k = 0; k < k_dir_tries; k++) {
                 const bool go = need_dir && !have;
                 if (pp_ballot(go) == 0) break;
+                if (STATS) { s_work[4]++; s_work[5] += (unsigned long long)__popcll(pp_ballot(go)); }
                 // (the cycle guard of device_math.hpp: the kMaxTries-th candidate is taken whatever it is)
                 if (go) { have = random_unit_sphere_try(dir_seed, p) || ++dir_tries >= (uint32_t)kMaxTries; }
             }
@@ -604,7 +631,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                     // the RNG state goes on with the path (:91 of the next bounce reads it); B also has a new throughput
                     if (store_throughput) aux[id] = make_uint4(f2u(dir_thr.x), f2u(dir_thr.y), f2u(dir_thr.z), dir_seed);
                     else reinterpret_cast<uint32_t *>(aux + id)[3] = dir_seed;
-                    dest = launch_ray(id, make_ray(dir_origin, dir_normal + p), dir_bounce, true);          // :134
+                    launch_ray(tr, make_ray(dir_origin, dir_normal + p), dir_bounce, true);                 // :134
                 } else {
                     if (store_throughput) aux[id] = make_uint4(f2u(dir_thr.x), f2u(dir_thr.y), f2u(dir_thr.z), dir_seed);
                     st4(qA + id * 16u, make_uint4(f2u(dir_origin.x), f2u(dir_origin.y), f2u(dir_origin.z), dir_seed));
@@ -617,31 +644,15 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
 
         if (q == QN) {
             // ============ N: pop stack entries until the path stands on a leaf (BVHTraversal.cuh:33-72) ============
-            Ray ray = make_ray(mk3(0, 0, 0), mk3(0, 0, 1));
-            float hit_t = FLT_MAX;
-            int sp = 0;
-            uint32_t cur = 0, end = 0, meta = 0;
-            bool shadow = false;
+            // (the loop itself is below, shared with the batches that launch rays)
             if (active) {
                 const uint4 A = ld4(qA + id * 16u), B = ld4(qB + id * 16u);
-                if (HBM || SUN) meta = ld1(meta_at(id));
-                sp = HBM ? (int)((meta >> 16) & 0xFFu) : (int)(B.w >> 24);
-                hit_t = u2f(A.w);
-                ray = make_ray(mk3(u2f(A.x), u2f(A.y), u2f(A.z)), mk3(u2f(B.x), u2f(B.y), u2f(B.z)));     // 1/dir again (Ray.cuh:7-9): 12 bytes of LDS per path saved
-                if (SUN) shadow = (meta & kShadow) != 0;
-            }
-            uint2 top = make_uint2(0u, 0u);
-            bool have_top = false;
-            for (uint32_t it = 0;; ++it) {
-                const bool go = active && dest < 0 && (have_top || sp > 0);
-                const unsigned long long m_go = pp_ballot(go);
-                // lanes that are done wait for the others only while enough of them are still popping
-                if (m_go == 0 || it >= pp.n_loop || (it > 0 && (uint32_t)__popcll(m_go) < pp.n_min_lanes)) break;
-                if (go) dest = pop_step(ray, hit_t, sp, id, cur, end, top, have_top);
-            }
-            if (active) {
-                if (dest < 0) { spill_top(sp, id, top, have_top); cur = end = 0; dest = sp > 0 ? QN : after_traversal(hit_t, shadow); }
-                store_trav(id, sp, cur, end, meta);
+                if (HBM || SUN) tr.meta = ld1(meta_at(id));
+                tr.sp = HBM ? (int)((tr.meta >> 16) & 0xFFu) : (int)(B.w >> 24);
+                tr.hit_t = u2f(A.w);
+                tr.ray = make_ray(mk3(u2f(A.x), u2f(A.y), u2f(A.z)), mk3(u2f(B.x), u2f(B.y), u2f(B.z)));     // 1/dir again (Ray.cuh:7-9): 12 bytes of LDS per path saved
+                if (SUN) tr.shadow = (tr.meta & kShadow) != 0;
+                tr.on = true;
             }
         } else if (q >= QT0 && q < QB) {
             // ============ T: the triangles of one leaf, two per step (Intersection.cu:4-36, BVHTraversal.cuh:46-57) ============
@@ -656,7 +667,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 ray.dir = mk3(u2f(B.x), u2f(B.y), u2f(B.z));
                 if (HBM || SUN) meta = ld1(meta_at(id));
                 if (HBM) {
-                    end = (int)(checked(ld1(meta_at(id) + 8u) - 1u, sc.n_tris, 0x100u) + 1u);         // [cur, end) within the triangles
+                    end = (int)(checked(ld1(meta_at(id) + 8u) - 1u, SC().n_tris, 0x100u) + 1u);         // [cur, end) within the triangles
                     cur = (int)min(B.w, (uint32_t)end);
                     sp = (int)((meta >> 16) & 0xFFu);
                 }
@@ -695,6 +706,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 for (;;) {
                     const bool go = left > 0;
                     if (pp_ballot(go) == 0) break;
+                    if (STATS) { s_work[2]++; s_work[3] += (unsigned long long)__popcll(pp_ballot(go)) + (unsigned long long)__popcll(pp_ballot(left > 1)); }    // (lane steps in half steps: triangles tested)
                     const bool two = left > 1;
                     const TriTest ta = fetch_tri_at(addr), tb = fetch_tri_at(addr + 48u);
                     float t0, u0, v0, t1, u1, v1;
@@ -751,7 +763,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 const uint32_t W = ld1(meta_at(id));
                 Ray ray; ray.orig = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); ray.dir = mk3(u2f(B.x), u2f(B.y), u2f(B.z)); ray.inv_dir = ray.dir;
                 const float hit_t = u2f(A.w);
-                const int hit_prim = (int)checked(prim_of(id, W), sc.n_tris, 0x800u);
+                const int hit_prim = (int)checked(prim_of(id, W), SC().n_tris, 0x800u);
                 uint32_t bounce = bounce_of(W);
                 // the barycentrics of the hit: the winning triangle's test once more (same inputs, same bits as in T)
                 float hit_u, hit_v, t_again;
@@ -765,17 +777,17 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 const TriCold cold = fetch_cold(hit_prim);                                 // :111-118
                 const MatDev mat = fetch_mat(cold.material);
                 if (mat.tex < 0) throughput = throughput * ld3(mat.albedo);
-                else throughput = throughput * tex_get_pixel<true>(sc, fetch_tex(mat.tex), interp_uv(cold, uvw));
+                else throughput = throughput * tex_get_pixel<true>(SC(), fetch_tex(mat.tex), interp_uv(cold, uvw));
                 const f3 origin = position + (normal * 0.001f);                            // :121
                 if (SUN) {
                     // :124-128: the sun's shadow ray starts where the bounce ray will (its origin waits in A), the normal is found
                     // again from the triangle and the side bit; the rest of this iteration is S's, after the shadow traversal
-                    const Ray sun_ray = make_ray(origin, ld3(fp.sunpos) + random_unit_vec3(seed) * 1.5f);
+                    const Ray sun_ray = make_ray(origin, ld3(FP().sunpos) + random_unit_vec3(seed) * 1.5f);
                     aux[id] = make_uint4(f2u(throughput.x), f2u(throughput.y), f2u(throughput.z), seed);
-                    dest = launch_shadow(id, sun_ray, make_meta((uint32_t)hit_prim, bounce, kHasSample | kShadow | (front_face ? 0u : kBackFace)));
+                    launch_shadow(tr, sun_ray, make_meta((uint32_t)hit_prim, bounce, kHasSample | kShadow | (front_face ? 0u : kBackFace)));
                 } else {
                     ++bounce;
-                    if ((int)bounce <= fp.bounce_limit) {                                  // :88 loop condition
+                    if ((int)bounce <= FP().bounce_limit) {                                  // :88 loop condition
                         need_dir = true; dir_origin = origin; dir_normal = normal; dir_seed = seed; dir_bounce = bounce; dir_tries = 0;
                         dir_thr = throughput;
                     } else {
@@ -793,12 +805,12 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 const uint32_t W = ld1(meta_at(id));
                 if (!(W & kOccluded)) {
                     float4 *const lp = aux_light + id;
-                    const f3 light = mk3(lp->x, lp->y, lp->z) + ld3(fp.suncol) * mk3(u2f(E.x), u2f(E.y), u2f(E.z));     // :126-127
+                    const f3 light = mk3(lp->x, lp->y, lp->z) + ld3(FP().suncol) * mk3(u2f(E.x), u2f(E.y), u2f(E.z));     // :126-127
                     *lp = make_float4(light.x, light.y, light.z, 0.0f);
                 }
                 const uint32_t bounce = bounce_of(W) + 1u;
-                if ((int)bounce <= fp.bounce_limit) {                                      // :88 loop condition
-                    const f3 fn = fetch_face_normal((int)checked(prim_of(id, W), sc.n_tris, 0x1000u));
+                if ((int)bounce <= FP().bounce_limit) {                                      // :88 loop condition
+                    const f3 fn = fetch_face_normal((int)checked(prim_of(id, W), SC().n_tris, 0x1000u));
                     need_dir = true; dir_origin = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); dir_normal = (W & kBackFace) ? (-1.f * fn) : fn;
                     dir_seed = E.w; dir_bounce = bounce; dir_tries = 0;
                 } else {
@@ -819,12 +831,12 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                     f3 light = mk3(0, 0, 0);
                     if (SUN) { const float4 l = aux_light[id]; light = mk3(l.x, l.y, l.z); }
                     if (!(hit_t < FLT_MAX))                                                // miss: :99-108
-                        light = light + sky_model(mk3(u2f(B.x), u2f(B.y), u2f(B.z)), ld3(fp.sky_color)) * mk3(u2f(E.x), u2f(E.y), u2f(E.z)) * fp.sky_intensity;
-                    if (fp.tone_mapping) light = uncharted2_filmic(light, fp.exposure);    // :165-169 (wave-uniform branches)
-                    if (fp.gamma_correction) light = gamma_correction(light);
-                    const uint32_t slot_ok = held(slot, fp.width * fp.local_rows * fp.n_frames, 0x8000u);
-                    if (fp.inline_resolve) accumulate_and_resolve(fp, slot_ok, light);     // one frame in the launch: slot = pixel
-                    else samples[slot_ok] = make_float4(light.x, light.y, light.z, 0.0f);
+                        light = light + sky_model(mk3(u2f(B.x), u2f(B.y), u2f(B.z)), ld3(FP().sky_color)) * mk3(u2f(E.x), u2f(E.y), u2f(E.z)) * FP().sky_intensity;
+                    if (FP().tone_mapping) light = uncharted2_filmic(light, FP().exposure);    // :165-169 (wave-uniform branches)
+                    if (FP().gamma_correction) light = gamma_correction(light);
+                    const uint32_t slot_ok = held(slot, FP().width * FP().local_rows * FP().n_frames, 0x8000u);
+                    if (FP().inline_resolve) accumulate_and_resolve(FP(), slot_ok, light);     // one frame in the launch: slot = pixel
+                    else ka->samples[slot_ok] = make_float4(light.x, light.y, light.z, 0.0f);
                 }
             }
             // Sample ids.  The first P of a workgroup are fixed (workgroup w starts with [w*P, (w+1)*P): the slots that wait in E's
@@ -837,14 +849,14 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
             // one has run dry; a slot retires only after every counter has been found dry.
             const bool initial = active && head + (uint32_t)lane < P;
             const uint32_t n_static = gridDim.x * P;
-            const uint32_t n_dynamic = pp.total_samples > n_static ? pp.total_samples - n_static : 0u;
+            const uint32_t n_dynamic = PA().total_samples > n_static ? PA().total_samples - n_static : 0u;
             uint32_t sid = initial ? blockIdx.x * P + head + (uint32_t)lane : 0xFFFFFFFFu;
             bool need = active && !initial;
             for (uint32_t attempt = 0; attempt < kSampleShards; ++attempt) {
                 const unsigned long long m = pp_ballot(need);
                 if (m == 0) break;
                 unsigned int base = 0;
-                if (lane == 0) base = atomicAdd(sample_counter + my_shard * kSampleShardStride, (unsigned int)__popcll(m));
+                if (lane == 0) base = atomicAdd(ka->sample_counter + my_shard * kSampleShardStride, (unsigned int)__popcll(m));
                 base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
                 if (need) {
                     const uint32_t j = base + (uint32_t)pp_rank(m);
@@ -854,33 +866,32 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 if (pp_ballot(need) != 0) my_shard = (my_shard + 1u) & (kSampleShards - 1u);        // this counter has run dry
             }
             if (active) {
-                if (sid >= pp.total_samples) {
+                if (sid >= PA().total_samples) {
                     st1_shared(ctrl + kCtrlExhausted, 1u);
                     lds_add(ctrl + kCtrlLive, 0xFFFFFFFFu);                                // this pool slot retires
                 } else {
                     // sample id -> (tile, frame, pixel): chunk = 64 samples = one 8x8 tile of one frame, frame-major, tile rows
-                    // visited with a stride (fp.row_step) -- the work order of wave_queue (DRT_CHUNK_ORDER 4)
+                    // visited with a stride (FP().row_step) -- the work order of wave_queue (DRT_CHUNK_ORDER 4)
                     const uint32_t my_chunk = sid >> 6, my_k = sid & 63u;
-                    const uint32_t n_tiles_all = pp.n_chunks / fp.n_frames;
+                    const uint32_t n_tiles_all = PA().n_chunks / FP().n_frames;
                     const uint32_t f_rel = my_chunk / n_tiles_all, tile = my_chunk - f_rel * n_tiles_all;
-                    uint32_t ty = tile / pp.tiles_x;
-                    const uint32_t tx = tile - ty * pp.tiles_x;
-                    ty = (ty * fp.row_step) % (n_tiles_all / pp.tiles_x);
+                    uint32_t ty = tile / PA().tiles_x;
+                    const uint32_t tx = tile - ty * PA().tiles_x;
+                    ty = (ty * FP().row_step) % (n_tiles_all / PA().tiles_x);
                     const uint32_t x = tx * 8u + (my_k & 7u), ly = ty * 8u + (my_k >> 3);
-                    if (x < fp.width && ly < fp.local_rows) {
-                        const uint32_t y = ((ly / fp.stripe_rows) * fp.world + fp.rank) * fp.stripe_rows + (ly % fp.stripe_rows);
-                        const uint32_t slot = f_rel * (fp.width * fp.local_rows) + ly * fp.width + x;
+                    if (x < FP().width && ly < FP().local_rows) {
+                        const uint32_t y = ((ly / FP().stripe_rows) * FP().world + FP().rank) * FP().stripe_rows + (ly % FP().stripe_rows);
+                        const uint32_t slot = f_rel * (FP().width * FP().local_rows) + ly * FP().width + x;
                         f2 screen_uv;
-                        screen_uv.x = ((float)x / (float)fp.width) * 2 - 1;
-                        screen_uv.y = ((float)y / (float)fp.height) * 2 - 1;
-                        uint32_t seed = x + y * fp.width;
-                        seed *= fp.frame_first + f_rel;
-                        const Ray ray = camera_get_ray(fp, screen_uv, seed);
-                        dest = launch_ray(id, ray, 0u, fp.bounce_limit >= 0);
+                        screen_uv.x = ((float)x / (float)FP().width) * 2 - 1;
+                        screen_uv.y = ((float)y / (float)FP().height) * 2 - 1;
+                        uint32_t seed = x + y * FP().width;
+                        seed *= FP().frame_first + f_rel;
+                        const Ray ray = camera_get_ray(FP(), screen_uv, seed);
+                        launch_ray(tr, ray, 0u, FP().bounce_limit >= 0);
                         aux[id] = make_uint4(f2u(1.0f), f2u(1.0f), f2u(1.0f), seed);
                         aux_slot[id] = slot;
                         if (SUN) aux_light[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                        if (fp.bounce_limit < 0) st1(qA + id * 16u + 12u, 0u);            // RayGen.cuh:88: the loop body never runs, the sample is black
                     } else {
                         st1(meta_at(id), HBM ? 0u : kNoPrim);       // a sample id outside the image (partial tile): the slot asks again
                         dest = QE;
@@ -888,19 +899,48 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const SceneV
                 }
             }
         }
+        if (q < QT0 || q >= QB) {
+            // ============ the N loop: the lanes of an N batch, and the rays this batch has just launched ============
+            // One visit per iteration (pop_step); a lane leaves when it stands on a leaf or its stack is empty.  Lanes that are
+            // done wait for the others only while enough of them are still popping; the rest goes (back) to the N queue.
+            for (uint32_t it = 0;; ++it) {
+                const bool go = tr.on && dest < 0 && (tr.have_top || tr.sp > 0);
+                const unsigned long long m_go = pp_ballot(go);
+                // (a launching batch: the root's visit always; further visits while enough of its lanes need one -- the others
+                // have their leaf or their miss already and wait)
+                if (m_go == 0 || it >= (q == QN ? k_n_loop : k_n_fuse_loop) || (it > 0 && (uint32_t)__popcll(m_go) < (q == QN ? k_n_min_lanes : k_n_fuse_min))) break;
+                if (STATS) { s_work[0]++; s_work[1] += (unsigned long long)__popcll(m_go); }
+                if (go) dest = pop_step(tr.ray, tr.hit_t, tr.sp, id, tr.cur, tr.end, tr.top, tr.have_top);
+            }
+            if (tr.on || tr.fresh) {
+                if (dest < 0) { spill_top(tr.sp, id, tr.top, tr.have_top); tr.cur = tr.end = 0; dest = tr.sp > 0 ? QN : after_traversal(tr.hit_t, tr.shadow); }
+                if (tr.fresh) {
+                    st4(qA + id * 16u, make_uint4(f2u(tr.ray.orig.x), f2u(tr.ray.orig.y), f2u(tr.ray.orig.z), tr.hit_store));
+                    if (HBM) {
+                        st4(qB + id * 16u, make_uint4(f2u(tr.ray.dir.x), f2u(tr.ray.dir.y), f2u(tr.ray.dir.z), tr.cur));
+                        st1(meta_at(id), tr.meta | ((uint32_t)tr.sp << 16));
+                        st1(meta_at(id) + 8u, tr.end);
+                    } else {
+                        st4(qB + id * 16u, make_uint4(f2u(tr.ray.dir.x), f2u(tr.ray.dir.y), f2u(tr.ray.dir.z), tr.cur | (tr.end << 12) | ((uint32_t)tr.sp << 24)));
+                        st1(meta_at(id), tr.meta);
+                    }
+                } else store_trav(id, tr.sp, tr.cur, tr.end, tr.meta);
+            }
+        }
         if (!HBM) __builtin_amdgcn_s_setprio(1);
         lds_release();
         push_group(dest, id);
-        if ((HBM || STATS) && pp_ballot(violations != 0) != 0) { if (violations != 0 && pp.status) atomicOr(pp.status, violations); violations = 0; }
+        if ((HBM || STATS) && pp_ballot(violations != 0) != 0) { if (violations != 0 && PA().status) atomicOr(PA().status, violations); violations = 0; }
         if (STATS) s_ticks[q] += __builtin_amdgcn_s_memtime() - s_t1;
     }
 
-    if (fp.span && lane == 0) atomicMax(&fp.span[1], (unsigned long long)wall_clock64());
-    if (STATS && pp.stats && lane == 0) {
-        for (int k = 0; k < kNQ; k++) { atomicAdd(&pp.stats[3 * k], s_batches[k]); atomicAdd(&pp.stats[3 * k + 1], s_lanes[k]); atomicAdd(&pp.stats[3 * k + 2], s_ticks[k]); }
-        atomicAdd(&pp.stats[3 * kNQ], s_claim); atomicAdd(&pp.stats[3 * kNQ + 1], s_idle); atomicAdd(&pp.stats[3 * kNQ + 2], s_lost);
-        atomicAdd(&pp.stats[3 * kNQ + 3], __builtin_amdgcn_s_memtime() - s_t_start);
-        atomicAdd(&pp.stats[3 * kNQ + 4], s_fail); atomicAdd(&pp.stats[3 * kNQ + 5], s_fail_ticks); atomicAdd(&pp.stats[3 * kNQ + 6], s_idle_ticks);
+    if (FP().span && lane == 0) atomicMax(&FP().span[1], (unsigned long long)wall_clock64());
+    if (STATS && PA().stats && lane == 0) {
+        for (int k = 0; k < kNQ; k++) { atomicAdd(&PA().stats[3 * k], s_batches[k]); atomicAdd(&PA().stats[3 * k + 1], s_lanes[k]); atomicAdd(&PA().stats[3 * k + 2], s_ticks[k]); }
+        atomicAdd(&PA().stats[3 * kNQ], s_claim); atomicAdd(&PA().stats[3 * kNQ + 1], s_idle); atomicAdd(&PA().stats[3 * kNQ + 2], s_lost);
+        atomicAdd(&PA().stats[3 * kNQ + 3], __builtin_amdgcn_s_memtime() - s_t_start);
+        for (int k = 0; k < 6; k++) atomicAdd(&PA().stats[3 * kNQ + 7 + k], s_work[k]);
+        atomicAdd(&PA().stats[3 * kNQ + 4], s_fail); atomicAdd(&PA().stats[3 * kNQ + 5], s_fail_ticks); atomicAdd(&PA().stats[3 * kNQ + 6], s_idle_ticks);
     }
 }
 
@@ -1013,7 +1053,7 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     else threads = std::max(256, std::min<int>({ kMaxPoolThreads, (int)P / 64 * 64, 1536 / groups / 64 * 64 }));
     // hbm-scene: every step waits for L2, so all the waves a workgroup can have (even a few more lanes than paths: measured on cs16_dust)
     if (hbm_scene && env_threads <= 0) threads = kMaxPoolThreads;
-    typedef void (*PoolKernel)(const SceneView, const FrameParams, const PoolParams, unsigned int *, float4 *);
+    typedef void (*PoolKernel)(const PoolArgs);
     static const PoolKernel kernels[16] = { path_pool_kernel<0>, path_pool_kernel<1>, path_pool_kernel<2>, path_pool_kernel<3>,
                                             path_pool_kernel<4>, path_pool_kernel<5>, path_pool_kernel<6>, path_pool_kernel<7>,
                                             path_pool_kernel<8>, path_pool_kernel<9>, path_pool_kernel<10>, path_pool_kernel<11>,
@@ -1037,6 +1077,7 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     pp.t_class[0] = t_class[0]; pp.t_class[1] = t_class[1]; pp.t_class[2] = t_class[2];
     pp.min_fill = (uint32_t)std::max(1, std::min(env_fill, 64)); pp.patience = (uint32_t)std::max(0, env_patience);
     pp.n_loop = (uint32_t)std::max(1, tune.n_loop); pp.n_min_lanes = (uint32_t)std::max(1, std::min(tune.n_min_lanes, 64));
+    pp.n_fuse_loop = (uint32_t)std::max(1, tune.n_fuse_loop); pp.n_fuse_min = (uint32_t)std::max(1, std::min(tune.n_fuse_min, 64));
     pp.cold_in_lds = cold_bytes > 0 ? 1u : 0u;
     pp.dir_tries = (uint32_t)std::max(1, tune.dir_tries);
     pp.status = status; pp.stats = tune.stats;
@@ -1073,7 +1114,9 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     if (launch_shape) { launch_shape[0] = (int)stack_entries; launch_shape[1] = per_cu; launch_shape[2] = (int)(lay.total / 1024); launch_shape[3] = threads; launch_shape[4] = (int)P; }
     FrameParams fq = fp;
     fq.inline_resolve = fp.n_frames == 1 ? 1 : 0;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)want), dim3(threads), lay.total, stream, sc, fq, pp, sample_counter, static_cast<float4 *>(samples));
+    PoolArgs args;
+    args.sc = sc; args.fp = fq; args.pp = pp; args.sample_counter = sample_counter; args.samples = static_cast<float4 *>(samples);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)want), dim3(threads), lay.total, stream, args);
     e = hipGetLastError();
     if (e != hipSuccess || fq.inline_resolve) return e;
     return launch_resolve(fp, samples, stream);

@@ -33,7 +33,7 @@ SRC = os.path.join(CSRC, "kernel_path_pool.hip")
 def makefile_flags():
     """COMMON + DEVFLAGS of the Makefile, so that the census is of the shipped code."""
     text = open(os.path.join(CSRC, "Makefile")).read()
-    common = re.search(r"^COMMON\s*:=\s*(.*)$", text, re.M).group(1).split()
+    common = [f for f in re.search(r"^COMMON\s*:=\s*(.*)$", text, re.M).group(1).split() if not f.startswith("$(")]
     dev = re.search(r"^DEVFLAGS\s*:=\s*(.*)$", text, re.M).group(1).replace("$(ARCH)", "gfx950").split()
     return common + dev
 

@@ -32,3 +32,9 @@ print("  claims given up: %d (%.2f per batch), %.1f%% of wave time; waiting for 
     st["failed_claims"], st["failed_claims"] / max(tot_b, 1), 100.0 * st["failed_claim_ticks"] / wt, 100.0 * st["idle_ticks"] / wt))
 print("  claim: %.1f%% of wave time, %.0f ticks per batch; idle polls %d (%.2f per batch); lost claims %d" % (
     100.0 * st["claim_ticks"] / wt, st["claim_ticks"] / max(tot_b, 1), st["idle_polls"], st["idle_polls"] / max(tot_b, 1), st["lost_claims"]))
+w = st.get("work")
+if w:
+    print("  lanes busy inside the loops: N %.1f of 64 over %.2f iterations per batch; T %.1f of 128 triangle slots per step, %.2f steps per batch; direction tries %.1f of 64 over %.2f iterations per B / R / S batch" % (
+        w["n_lane_pops"] / max(w["n_iterations"], 1), w["n_iterations"] / max(st["N"][0], 1),
+        w["t_lane_tests"] / max(w["t_steps"], 1), w["t_steps"] / max(sum(st[q][0] for q in ("T0", "T1", "T2", "T3")), 1),
+        w["dir_lane_tries"] / max(w["dir_iterations"], 1), w["dir_iterations"] / max(st["B"][0] + st["R"][0] + st["S"][0], 1)))
