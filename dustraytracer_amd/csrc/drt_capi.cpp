@@ -701,7 +701,7 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
             }
             unsigned int *const queue_head = r->tile_counter + (size_t)(r->counters_used++) * kQueueHeadBlockWords;
             bool pool_hbm_scene = false;
-            if (r->use_path_pool && !r->counting && !material_ext &&
+            if (r->use_path_pool && !material_ext &&
                 path_pool_supports(r->view, fp, r->bvh_depth, wave_queue_scene_lds_bytes(r->view), &pool_hbm_scene) && (r->pool_launched = true))
                 HIP_TRY(launch_path_pool(r->view, fp, r->bvh_depth, r->scene_has_alpha, pool_hbm_scene, r->pool_t_class, r->pool_tuning, r->pool_scratch, queue_head, r->samples, r->pool_status,
                                          r->num_cus, r->stream, &r->kernel_name, r->launch_shape));

@@ -267,6 +267,13 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
     // (branch-free -- a branch between the loads of a step would serialise them: the index is clamped, the violation noted in a
     // register and reported once, after the batch)
     uint32_t violations = 0;
+    // statistics build: the exact work counters of drt_counters (samples, rays, node visits, interior visits, triangle tests, textured /
+    // flat hits, shadow rays, their interior visits and triangle tests) -- counted per lane where the reference's loops would
+    // count them (oracle/drt_oracle.c), summed at the end; FrameParams::counters != nullptr asks for them
+    enum : int { C_SAMPLES = 0, C_RAYS, C_NODES, C_INNER, C_TRIS, C_HTEX, C_HFLAT, C_SRAYS, C_SINNER, C_STRIS, C_COUNT };
+    uint32_t work[C_COUNT];
+    for (int k = 0; k < C_COUNT; k++) work[k] = 0;
+    auto count = [&](int what, uint32_t n = 1u) { if (STATS) work[what] += n; };
     auto checked = [&](uint32_t index, uint32_t limit, unsigned int code) -> uint32_t {
         if (!(HBM || STATS)) return index;
         violations |= index >= limit ? code : 0u;
@@ -397,15 +404,17 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
     // and popped again at once: it never goes through LDS), else the stack's top.  Returns the T queue when the path now stands on
     // a leaf ([cur, end) = its triangles), else -1 (entry culled, or an interior node: its far child went on
     // the stack, its near child -- the next visit -- into `top`).  (ray.dir is not used: the slab test needs origin and 1/dir.)
-    auto pop_step = [&](const Ray &ray, float hit_t, int &sp, uint32_t id, uint32_t &cur, uint32_t &end, uint2 &top, bool &have_top) -> int {
+    auto pop_step = [&](const Ray &ray, float hit_t, int &sp, uint32_t id, uint32_t &cur, uint32_t &end, uint2 &top, bool &have_top, bool shadow) -> int {
         uint2 e = top;
         if (!have_top) { --sp; e = stack_load(sp, id); }
         have_top = false;
         int dest = -1;
         // :41 (without a hit, hit_t = FLT_MAX > dist); :38 was applied when the root was pushed
         if (!(hit_t < u2f(e.y))) {
+            if (!shadow) count(C_NODES);                          // :43 (RayTest keeps no heat map)
             if (e.x & kLeafBit) dest = leaf_state(e.x & ~kLeafBit, cur, end);
             else {
+                count(shadow ? C_SINNER : C_INNER);
                 const ChildPair c = fetch_children(e.x);
                 const float d1 = slab_entry_or_inf(c.min1, c.max1, ray);
                 const float d2 = slab_entry_or_inf(c.min2, c.max2, ray);
@@ -416,7 +425,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                 if (db < hit_t) {
                     // the near child is this path's next visit and passes :41 (nothing changes hit_t in between): a leaf goes
                     // straight to T, an interior node stays in registers
-                    if (rb & kLeafBit) dest = leaf_state(rb & ~kLeafBit, cur, end);
+                    if (rb & kLeafBit) { dest = leaf_state(rb & ~kLeafBit, cur, end); if (!shadow) count(C_NODES); }     // (its pop, which passes :41)
                     else { top = make_uint2(rb, f2u(db)); have_top = true; }
                 }
             }
@@ -492,12 +501,14 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
     auto launch_ray = [&](Trav &t, const Ray &ray, uint32_t bounce, bool trace) {
         uint2 top = make_uint2(0u, 0u);
         const bool have_top = trace && begin_closest(ray, top);
+        if (trace) count(C_RAYS);                        // TraceRay.cu:15
         launch_with(t, ray, make_meta(kNoPrim, bounce, kHasSample), top, have_top, false);
         if (!trace) t.hit_store = 0u;                 // RayGen.cuh:88: the loop body never runs, the sample is black (E adds no sky light)
     };
     // RayTest (BVHTraversal.cuh:76-134): the root is visited unless its slab test says "behind" (:95-103), no distance culls
     auto launch_shadow = [&](Trav &t, const Ray &ray, uint32_t w_word) {
         const bool have_top = SC().root_ref != kNoNode && !(slab_intersect(root_min, root_max, ray) < 0);
+        count(C_SRAYS);
         launch_with(t, ray, w_word, make_uint2(root_ref, f2u(0.0f)), have_top, true);
     };
 
@@ -691,7 +702,10 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                         float t, u, v;
                         const bool h = tri_intersect_flat(ray, tri[k].v0, tri[k].e1, tri[k].e2, t, u, v) & (first + k < end);
                         if (SUN && shadow) {
-                            if (h && (!ALPHA || alpha_test(idx[k], mk3(1.0f - u - v, u, v)))) { occluded = true; cur = end; sp = 0; }
+                            if (STATS && first + k < end && !occluded) count(C_STRIS);
+                            if (h && !occluded && (!ALPHA || alpha_test(idx[k], mk3(1.0f - u - v, u, v)))) { occluded = true; cur = end; sp = 0; }
+                        } else if (STATS && first + k < end) count(C_TRIS);
+                        if (SUN && shadow) {
                         } else if (h && t < hit_t && (!ALPHA || alpha_test(idx[k], mk3(1.0f - u - v, u, v)))) { hit_t = t; hit_prim = (uint32_t)idx[k]; }
                     }
                 }
@@ -714,10 +728,12 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                     const bool h1 = tri_intersect_flat(ray, tb.v0, tb.e1, tb.e2, t1, u1, v1) & two;
                     const int i = cur, j = cur + 1;
                     if (SUN && shadow) {                                  // RayTest: any accepted hit ends the traversal (:105-117)
-                        const bool occ = (h0 && (!ALPHA || alpha_test(i, mk3(1.0f - u0 - v0, u0, v0)))) ||
-                                         (h1 && (!ALPHA || alpha_test(j, mk3(1.0f - u1 - v1, u1, v1))));
+                        const bool occ0 = h0 && (!ALPHA || alpha_test(i, mk3(1.0f - u0 - v0, u0, v0)));
+                        const bool occ = occ0 || (h1 && (!ALPHA || alpha_test(j, mk3(1.0f - u1 - v1, u1, v1))));
+                        if (STATS && go) count(C_STRIS, occ0 || !two ? 1u : 2u);          // (the reference stops at the first accepted hit)
                         if (occ) { occluded = true; left = 0; sp = 0; }
                     } else {
+                        if (STATS && go) count(C_TRIS, two ? 2u : 1u);
                         // (the barycentrics are not kept: B computes them again for the one triangle that wins)
                         if (h0 && t0 < hit_t && (!ALPHA || alpha_test(i, mk3(1.0f - u0 - v0, u0, v0)))) { hit_t = t0; hit_prim = (uint32_t)i; }
                         if (h1 && t1 < hit_t && (!ALPHA || alpha_test(j, mk3(1.0f - u1 - v1, u1, v1)))) { hit_t = t1; hit_prim = (uint32_t)j; }
@@ -739,7 +755,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                 while (sp > 0) {
                     const uint2 e = stack_load(sp - 1, id);
                     if (hit_t < u2f(e.y)) { --sp; continue; }
-                    if (e.x & kLeafBit) { --sp; dest = leaf_state(e.x & ~kLeafBit, next_cur, next_end); }
+                    if (e.x & kLeafBit) { --sp; dest = leaf_state(e.x & ~kLeafBit, next_cur, next_end); if (!(SUN && shadow)) count(C_NODES); }
                     break;
                 }
                 if (dest < 0) dest = sp > 0 ? QN : after_traversal(hit_t, shadow);
@@ -776,6 +792,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                 const bool front_face = closest_hit_frame(ray, hit_t, fetch_face_normal(hit_prim), position, normal);
                 const TriCold cold = fetch_cold(hit_prim);                                 // :111-118
                 const MatDev mat = fetch_mat(cold.material);
+                count(mat.tex < 0 ? C_HFLAT : C_HTEX);
                 if (mat.tex < 0) throughput = throughput * ld3(mat.albedo);
                 else throughput = throughput * tex_get_pixel<true>(SC(), fetch_tex(mat.tex), interp_uv(cold, uvw));
                 const f3 origin = position + (normal * 0.001f);                            // :121
@@ -887,6 +904,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                         screen_uv.y = ((float)y / (float)FP().height) * 2 - 1;
                         uint32_t seed = x + y * FP().width;
                         seed *= FP().frame_first + f_rel;
+                        count(C_SAMPLES);
                         const Ray ray = camera_get_ray(FP(), screen_uv, seed);
                         launch_ray(tr, ray, 0u, FP().bounce_limit >= 0);
                         aux[id] = make_uint4(f2u(1.0f), f2u(1.0f), f2u(1.0f), seed);
@@ -910,7 +928,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                 // have their leaf or their miss already and wait)
                 if (m_go == 0 || it >= (q == QN ? k_n_loop : k_n_fuse_loop) || (it > 0 && (uint32_t)__popcll(m_go) < (q == QN ? k_n_min_lanes : k_n_fuse_min))) break;
                 if (STATS) { s_work[0]++; s_work[1] += (unsigned long long)__popcll(m_go); }
-                if (go) dest = pop_step(tr.ray, tr.hit_t, tr.sp, id, tr.cur, tr.end, tr.top, tr.have_top);
+                if (go) dest = pop_step(tr.ray, tr.hit_t, tr.sp, id, tr.cur, tr.end, tr.top, tr.have_top, SUN && tr.shadow);
             }
             if (tr.on || tr.fresh) {
                 if (dest < 0) { spill_top(tr.sp, id, tr.top, tr.have_top); tr.cur = tr.end = 0; dest = tr.sp > 0 ? QN : after_traversal(tr.hit_t, tr.shadow); }
@@ -935,6 +953,10 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
     }
 
     if (FP().span && lane == 0) atomicMax(&FP().span[1], (unsigned long long)wall_clock64());
+    if (STATS && FP().counters) {
+        // (wave sums by DPP-free butterfly through ds_bpermute would save atomics; a counting launch is not timed)
+        for (int k = 0; k < C_COUNT; k++) if (work[k]) atomicAdd(&FP().counters[k], (unsigned long long)work[k]);
+    }
     if (STATS && PA().stats && lane == 0) {
         for (int k = 0; k < kNQ; k++) { atomicAdd(&PA().stats[3 * k], s_batches[k]); atomicAdd(&PA().stats[3 * k + 1], s_lanes[k]); atomicAdd(&PA().stats[3 * k + 2], s_ticks[k]); }
         atomicAdd(&PA().stats[3 * kNQ], s_claim); atomicAdd(&PA().stats[3 * kNQ + 1], s_idle); atomicAdd(&PA().stats[3 * kNQ + 2], s_lost);
@@ -1047,7 +1069,7 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     }
     const PoolLayout lay = pool_layout(P, ring_cap, stack_entries, scene_bytes, cold_bytes, n_rings, word_bytes, stack_entry_bytes);
     if (lay.total > 160u * 1024u) return hipErrorInvalidValue;
-    const int flags = (tune.stats ? 1 : 0) | (fp.enable_sunlight ? 2 : 0) | (scene_has_alpha ? 4 : 0) | (hbm_scene ? 8 : 0);
+    const int flags = ((tune.stats || fp.counters) ? 1 : 0) | (fp.enable_sunlight ? 2 : 0) | (scene_has_alpha ? 4 : 0) | (hbm_scene ? 8 : 0);
     int threads;
     if (env_threads > 0) threads = std::max(64, std::min(env_threads, kMaxPoolThreads) / 64 * 64);
     else threads = std::max(256, std::min<int>({ kMaxPoolThreads, (int)P / 64 * 64, 1536 / groups / 64 * 64 }));

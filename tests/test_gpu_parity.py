@@ -220,23 +220,34 @@ def test_renderer_state_machine(renderer):
     assert not renderer.GetAccumulationBuffer().any()
 
 
-def test_counters_match_oracle(renderer):
-    sc, osc = make_pair("cornell_box")
-    cam, ocam = cameras("cornell_box")
-    s, o = settings_pair(ray_bounce_limit=8, enableSunlight=1)
-    renderer.m_RendererSettings = s
-    renderer.ResizeBuffer(96, 54)
-    renderer.resetAccumulationBuffer()
-    renderer.setCounting(True)
-    try:
-        renderer.RenderBatch(cam, sc, 2)
-        got = renderer.getCounters().as_dict()
-    finally:
-        renderer.setCounting(False)
-    _, _, cnt = oracle.render(osc, ocam, o, 96, 54, 1, 2, want_counters=True)
+@pytest.mark.parametrize("scene,kw", [("cornell_box", dict(ray_bounce_limit=8, enableSunlight=1)), ("cornell_box", dict(ray_bounce_limit=8)),
+                                      ("room", dict(ray_bounce_limit=6)), ("suzanne_plane", dict(ray_bounce_limit=3, enableSunlight=1)),
+                                      ("mc_transparency", dict(ray_bounce_limit=4, enableSunlight=1)), ("uv_texture_test", dict(ray_bounce_limit=3))])
+def test_counters_match_oracle(renderer, scene, kw):
+    """drt_counters are counted by the tracing kernel that is measured -- path_pool's statistics build (FLAGS & 1), in every
+    variant: scene in LDS / read from global memory, sunlight, alpha cut-outs -- and equal the oracle's counts exactly: SURVEY 8(d)'s
+    algorithmic bytes are a function of them.  The general wave_queue kernel (debug views, the material model) counts the same."""
+    sc, osc = make_pair(scene)
+    cam, ocam = cameras(scene)
+    s, o = settings_pair(**kw)
+    ref, _, cnt = oracle.render(osc, ocam, o, 96, 54, 1, 2, want_counters=True)
     want = cnt.as_dict()
-    for k, v in got.items():
-        assert v == want[k], k
+    names = ("samples", "rays", "node_visits", "inner_visits", "tri_tests", "hits_textured", "hits_flat", "shadow_rays", "inner_visits_shadow", "tri_tests_shadow")
+    for kernel, r in (("path_pool", renderer), ("wave_queue", _renderer_with_env({"DRT_KERNEL": "wave_queue"}))):
+        r.m_RendererSettings = s
+        r.ResizeBuffer(96, 54)
+        r.resetAccumulationBuffer()
+        r.setCounting(True)
+        try:
+            r.RenderBatch(cam, sc, 2)
+            got = r.getCounters().as_dict()
+            assert kernel in r.kernelInfo()
+            image = r.GetRenderTargetImage()
+        finally:
+            r.setCounting(False)
+        compare(image, ref, "%s %r, counting build of %s" % (scene, kw, kernel))
+        for k in names:
+            assert got[k] == want[k], (kernel, k, got[k], want[k])
 
 
 @pytest.mark.parametrize("stripe_rows,world", [(8, 2), (8, 8), (16, 3), (5, 4)])
