@@ -104,7 +104,7 @@ def cpu_baseline(scene_key, W, H, depth, target_seconds):
 def load_profile(workload):
     """Per-launch counter averages of the tracing kernel on this workload (SQ instruction / lane counters, HBM bytes), written
     by tools/roofline_from_profiles.py from rocprofv3 --pmc passes of this same bench (tools/collect_profiles.sh); else None."""
-    for rnd in ("r02",):
+    for rnd in ("r03", "r02"):
         path = os.path.join(ROOT, "profiles", "%s_roofline_%s.json" % (rnd, workload))
         try:
             with open(path) as f:
@@ -117,6 +117,34 @@ def load_profile(workload):
 
 
 VALU_PEAK_GSLOTS = 1024 * 2.4e9 / 2 / 1e9     # 256 CUs x 4 SIMDs, 2.4 GHz, one wave64 add / mul / min / max issues every 2 cycles
+
+
+def algorithmic_slots(counters):
+    """VALU issue slots the REFERENCE's arithmetic needs for this launch's exact work (counted by the measured kernel itself):
+    sum over the reference's operations of (work counter x issue slots of one call of that operation in the shipped arithmetic,
+    profiles/r03_isa_slots.json, made by tools/isa_by_phase.py --slots-json from tools/probes/isa_probes.hip), per lane; / 64 =
+    wave instructions at full lane utilisation.  Queues, state traffic, address arithmetic and everything else the kernel adds
+    are NOT in it: algorithmic_frac = this / kernel time / peak is the fraction of a VALU-bound ideal."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_isa_slots.json")) as f:
+            per_call = {k: v["slots"] for k, v in json.load(f)["per_call"].items()}
+    except (OSError, ValueError, KeyError):
+        return None
+    c = counters
+    terms = {
+        "triangle tests (Intersection.cu:4-36)": (c["tri_tests"] + c["tri_tests_shadow"]) * per_call["tri_test"],
+        "child-box slab tests (Bounds.cu:18-41), two per interior visit": 2 * (c["inner_visits"] + c["inner_visits_shadow"]) * per_call["box_test"],
+        "bounce-direction candidates (Random.cu:50-58)": c.get("sampler_tries", 0) * per_call["sampler_try"],
+        "closest-hit frame + throughput (ClosestHit.cuh:13-24, RayGen.cuh:112,121)": (c["hits_textured"] + c["hits_flat"]) * per_call["shade_hit"],
+        "texel fetch + decode (Texture.cu:33-58)": c["hits_textured"] * per_call["texture_fetch"],
+        "ray set-up: 1/dir + the root's slab test (Ray.cuh:7-9, BVHTraversal.cuh:22-26)": c["rays"] * per_call["ray_setup"],
+        "shadow-ray set-up (RayGen.cuh:124-125)": c["shadow_rays"] * per_call["shadow_ray_setup"],
+        "per sample: camera ray, sky, tone map, gamma (Camera.cu:82-123, RayGen.cuh:23-61)": c["samples"] * per_call["sample"],
+    }
+    lane_slots = float(sum(terms.values()))
+    return {"wave_issue_slots_per_launch": lane_slots / 64.0, "lane_slots_per_sample": round(lane_slots / max(c["samples"], 1), 1),
+            "share": {k: round(v / lane_slots, 4) for k, v in terms.items() if v}, "slots_per_call": per_call,
+            "slots_from": "profiles/r03_isa_slots.json"}
 
 
 def main_group(args):
@@ -360,18 +388,37 @@ def main():
                         "kernel_ms_stream_events": round(events_ms, 4), "launches_per_step": iso_launches,
                         "kernel_ms_in_flight": round(sum(span_ms) / max(len(span_ms), 1) / iso_launches, 4),
                         "note": ("branchy scalar fp32 / u32 code, scene and path state in LDS: vector-ALU issue bounds the kernel, HBM does not. "
-                                 "achieved = (SQ_INSTS_VALU + SQ_INSTS_VALU_FMA_F32 + 3 SQ_INSTS_VALU_TRANS_F32) per launch [rocprofv3 --pmc, profiles/] / kernel_ms "
+                                 "frac = frac_alone: achieved = (SQ_INSTS_VALU + SQ_INSTS_VALU_FMA_F32 + 3 SQ_INSTS_VALU_TRANS_F32) per launch [rocprofv3 --pmc, profiles/] / kernel_ms "
                                  "[this run: the tracing kernel alone, device clock; = rocprofv3 --kernel-trace duration]; issue costs 2 / 4 / 8 cycles measured "
                                  "(tools/microbench/valu_issue.hip); compares and conversions priced at 2, so frac is a lower bound of the pipe's occupancy. "
-                                 "kernel_ms_in_flight: the same span while %d frames share the GPU (not a kernel time)" % len(slots))}
+                                 "kernel_ms_in_flight: the same span while %d frames share the GPU (not a kernel time). frac_timed: the same slots x launches per step / ms_per_step (the timed region). "
+                                 "algorithmic_frac: the issue slots of the reference's arithmetic alone (exact work counters x per-operation slots of the shipped ISA) at full lane "
+                                 "utilisation, over the same times" % len(slots))}
             if same_kernel and prof.get("valu_issue_slots_per_launch"):
                 ach = prof["valu_issue_slots_per_launch"] * share / (kernel_ms * 1e-3) / 1e9
-                roofline.update({"achieved": round(ach, 1), "frac": round(ach / VALU_PEAK_GSLOTS, 4),
+                # the same slots over the TIMED region: all launches of a step / ms_per_step (several frames in flight share the chip)
+                ach_timed = prof["valu_issue_slots_per_launch"] * share * iso_launches / (ms_per_step * 1e-3) / 1e9
+                roofline.update({"achieved": round(ach, 1), "frac": round(ach / VALU_PEAK_GSLOTS, 4), "frac_alone": round(ach / VALU_PEAK_GSLOTS, 4),
+                                 "frac_timed": round(ach_timed / VALU_PEAK_GSLOTS, 4),
                                  "lane_utilisation": round(prof.get("lane_utilisation", 0.0), 4),
                                  "valu_wave_instructions_per_launch": int(prof["per_launch"].get("SQ_INSTS_VALU", 0) * share),
                                  "counters_from": prof["_file"] + ("" if share == 1.0 else " (full-frame launch, scaled by this rank's share of the samples)")})
             if same_kernel and prof.get("hbm_bytes_per_launch"):
                 roofline["traffic"] = int(prof["hbm_bytes_per_launch"] * share)
+            if same_kernel:
+                for key in ("wave_time", "l2"):
+                    if prof.get(key):
+                        roofline[key] = prof[key]
+            if counters is not None:
+                alg = algorithmic_slots(counters)
+                if alg:
+                    alg_launch = alg["wave_issue_slots_per_launch"] / iso_launches
+                    alg["wave_issue_slots_per_launch"] = int(alg_launch)
+                    roofline["algorithmic_frac"] = round(alg_launch / (kernel_ms * 1e-3) / 1e9 / VALU_PEAK_GSLOTS, 4)
+                    roofline["algorithmic_frac_timed"] = round(alg_launch * iso_launches / (ms_per_step * 1e-3) / 1e9 / VALU_PEAK_GSLOTS, 4)
+                    if roofline.get("valu_wave_instructions_per_launch"):
+                        alg["of_issued_slots"] = round(alg_launch / (prof["valu_issue_slots_per_launch"] * share), 4)
+                    roofline["algorithmic"] = alg
             if alg_bytes is not None:
                 alg_launch = alg_bytes / iso_launches          # (counted on this rank's own launches)
                 hbm = {"algorithmic_bytes_per_launch": int(alg_launch), "bytes_per_sample": round(alg_bytes / max(counters["samples"], 1), 1),

@@ -154,7 +154,7 @@ class _TexInfo(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("samples", "rays", "node_visits", "inner_visits", "tri_tests",
                                            "hits_textured", "hits_flat", "shadow_rays", "inner_visits_shadow",
-                                           "tri_tests_shadow")] + [("phase_execs", C.c_uint64 * 4), ("phase_lanes", C.c_uint64 * 4), ("phase_ticks", C.c_uint64 * 4), ("wave_ticks", C.c_uint64)]
+                                           "tri_tests_shadow")] + [("phase_execs", C.c_uint64 * 4), ("phase_lanes", C.c_uint64 * 4), ("phase_ticks", C.c_uint64 * 4), ("wave_ticks", C.c_uint64), ("sampler_tries", C.c_uint64)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, t in self._fields_ if t is C.c_uint64 and n != "wave_ticks"}

@@ -101,7 +101,7 @@ struct FrameParams {
     uint32_t stripe_rows, rank, world, local_rows;
     float *accum;                    // float3[width*local_rows]
     float *rgba;                     // float4[width*local_rows]
-    unsigned long long *counters;    // drt_counters as 23 x u64, or nullptr
+    unsigned long long *counters;    // drt_counters as 24 x u64, or nullptr
     unsigned long long *span;        // wave_queue: {max(~start), max(end)} of the kernel on the constant-rate wall clock, or nullptr
     // wave_queue phase voting: a phase other than T runs as soon as this many lanes wait for it
     int32_t vote_node, vote_shade, vote_dir, vote_spec;

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
     // statistics build: the exact work counters of drt_counters (samples, rays, node visits, interior visits, triangle tests, textured /
     // flat hits, shadow rays, their interior visits and triangle tests) -- counted per lane where the reference's loops would
     // count them (oracle/drt_oracle.c), summed at the end; FrameParams::counters != nullptr asks for them
-    enum : int { C_SAMPLES = 0, C_RAYS, C_NODES, C_INNER, C_TRIS, C_HTEX, C_HFLAT, C_SRAYS, C_SINNER, C_STRIS, C_COUNT };
+    enum : int { C_SAMPLES = 0, C_RAYS, C_NODES, C_INNER, C_TRIS, C_HTEX, C_HFLAT, C_SRAYS, C_SINNER, C_STRIS, C_TRIES, C_COUNT };
     uint32_t work[C_COUNT];
     for (int k = 0; k < C_COUNT; k++) work[k] = 0;
     auto count = [&](int what, uint32_t n = 1u) { if (STATS) work[what] += n; };
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                 if (pp_ballot(go) == 0) break;
                 if (STATS) { s_work[4]++; s_work[5] += (unsigned long long)__popcll(pp_ballot(go)); }
                 // (the cycle guard of device_math.hpp: the kMaxTries-th candidate is taken whatever it is)
-                if (go) { have = random_unit_sphere_try(dir_seed, p) || ++dir_tries >= (uint32_t)kMaxTries; }
+                if (go) { count(C_TRIES); have = random_unit_sphere_try(dir_seed, p) || ++dir_tries >= (uint32_t)kMaxTries; }
             }
             if (need_dir) {
                 if (have) {
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
     if (FP().span && lane == 0) atomicMax(&FP().span[1], (unsigned long long)wall_clock64());
     if (STATS && FP().counters) {
         // (wave sums by DPP-free butterfly through ds_bpermute would save atomics; a counting launch is not timed)
-        for (int k = 0; k < C_COUNT; k++) if (work[k]) atomicAdd(&FP().counters[k], (unsigned long long)work[k]);
+        for (int k = 0; k < C_COUNT; k++) if (work[k]) atomicAdd(&FP().counters[k == C_TRIES ? 23 : k], (unsigned long long)work[k]);     // (drt_counters: the ten work counters, 13 words of wave_queue's phase statistics, sampler_tries)
     }
     if (STATS && PA().stats && lane == 0) {
         for (int k = 0; k < kNQ; k++) { atomicAdd(&PA().stats[3 * k], s_batches[k]); atomicAdd(&PA().stats[3 * k + 1], s_lanes[k]); atomicAdd(&PA().stats[3 * k + 2], s_ticks[k]); }

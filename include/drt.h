@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define DRT_ABI_VERSION 1
+/* 2: drt_counters grew by sampler_tries; drt_group_* and drt_material_model entry points (round 2) are part of it */
+#define DRT_ABI_VERSION 2
 
 typedef enum {
     DRT_OK = 0,
@@ -120,6 +121,7 @@ typedef struct drt_counters {
     /* wave_queue kernel only: executions of the T / N / S / R phase (per wave) and lanes served by them */
     uint64_t phase_execs[4], phase_lanes[4];
     uint64_t phase_ticks[4], wave_ticks;   /* counting build: shader-clock ticks per phase / per wave lifetime, summed over waves */
+    uint64_t sampler_tries;                /* path_pool: candidates drawn by randomUnitSphereVec3 (Random.cu:50-58) for bounce directions */
 } drt_counters;
 
 typedef struct drt_scene drt_scene;         /* replaces struct Scene, Core/Scene/Scene.cuh:41-57 */

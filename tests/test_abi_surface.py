@@ -34,7 +34,7 @@ def test_python_binding_covers_the_header():
 
 
 def test_abi_version_and_defaults_without_gpu():
-    assert drt._lib.drt_abi_version() == 1
+    assert drt._lib.drt_abi_version() == 2
     s = drt.RendererSettings()
     assert (s.max_samples, s.ray_bounce_limit, s.gamma_correction, s.tone_mapping, s.enableSunlight) == (500, 2, 1, 1, 0)
     assert abs(s.sky_intensity - 20) < 1e-6 and abs(s.sunlight_intensity - 30) < 1e-6

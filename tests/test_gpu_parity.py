@@ -248,6 +248,8 @@ def test_counters_match_oracle(renderer, scene, kw):
         compare(image, ref, "%s %r, counting build of %s" % (scene, kw, kernel))
         for k in names:
             assert got[k] == want[k], (kernel, k, got[k], want[k])
+        if kernel == "path_pool":
+            assert got["sampler_tries"] == want["sphere_iters"]
 
 
 @pytest.mark.parametrize("stripe_rows,world", [(8, 2), (8, 8), (16, 3), (5, 4)])

@@ -46,6 +46,8 @@ def phase_regions():
         m = re.search(r"// =+ ([A-Z][0-9A-Za-z]*)\b.*=+\s*$", l)
         if m:
             marks.append((i, m.group(1)))
+        elif "// ============ the N loop" in l:
+            marks.append((i, "NLOOP"))
         elif "---------------- choose a queue" in l:
             marks.append((i, "claim"))
         elif re.search(r"^\s+if \(!HBM\) __builtin_amdgcn_s_setprio\(1\);\s*$", l) and marks and marks[-1][1] not in ("claim", "prologue"):
@@ -128,6 +130,7 @@ def census(flags, keep=None):
         return "setup"
 
     table = collections.defaultdict(lambda: collections.Counter())
+    sites = collections.defaultdict(set)
     for (addr, mn), st in zip(insts, stacks):
         frames = [(st[i], st[i + 1]) for i in range(0, len(st) - 1, 2)]      # (function, file:line:col), innermost first
         outer_line = 0
@@ -152,14 +155,93 @@ def census(flags, keep=None):
         c = table[(ph, op)]
         c[classify(mn)] += 1
         c["slots"] += slots(mn)
+        # the call site of `op` (the location in the frame just outside it): distinct call sites = inlined copies
+        for i, (fn, loc) in enumerate(frames):
+            if fn == op and i + 1 < len(frames):
+                sites[(ph, op)].add(frames[i + 1][1])
+                break
+    for key, c in table.items():
+        c["copies"] = max(1, len(sites.get(key, ())))
     return table, len(insts)
+
+
+# ---- per-operation cost: tools/probes/isa_probes.hip, one kernel per reference operation, compiled with the Makefile's flags ----
+COLD_LINES = None
+
+
+def cold_lines():
+    """device_math.hpp lines whose code runs only outside 2^-100..2^100 (the plain operator behind exact_rcp / exact_sqrt)."""
+    global COLD_LINES
+    if COLD_LINES is None:
+        COLD_LINES = set()
+        for i, l in enumerate(open(os.path.join(CSRC, "device_math.hpp")).read().split("\n"), 1):
+            if re.search(r"__builtin_expect\(.*\) q = 1\.0f / x;|return sqrtf\(x\);", l):
+                COLD_LINES.add(i)
+    return COLD_LINES
+
+
+def probe_slots():
+    """{operation: VALU issue slots of one call} from the probe kernels (cold fallback paths excluded, empty probe subtracted)."""
+    tmp = tempfile.mkdtemp(prefix="isa_probes_")
+    elf = os.path.join(tmp, "probes.elf")
+    src = os.path.join(ROOT, "tools", "probes", "isa_probes.hip")
+    cmd = ["/opt/rocm/bin/hipcc"] + makefile_flags() + ["-gline-tables-only", "--cuda-device-only", "--no-gpu-bundle-output", "-c", src, "-o", elf]
+    subprocess.run(cmd, check=True, cwd=CSRC, stderr=subprocess.DEVNULL)
+    dis = subprocess.run([LLVM + "/llvm-objdump", "-d", "--no-show-raw-insn", elf], check=True, capture_output=True, text=True).stdout
+    per = collections.OrderedDict()
+    cur = None
+    for line in dis.split("\n"):
+        m = re.match(r"^([0-9a-f]{16}) <(.*)>:", line)
+        if m:
+            k = re.search(r"probe_(\w+?)(?:PK|P[fK]|Pf)", m.group(2))
+            cur = k.group(1) if k else None
+            if cur:
+                per[cur] = []
+            continue
+        m = re.match(r"^\s+(\S+).*//\s*([0-9A-F]{12}):", line)
+        if m and cur:
+            per[cur].append((int(m.group(2), 16), m.group(1)))
+    out = {}
+    for name, insts in per.items():
+        sym = subprocess.run([LLVM + "/llvm-symbolizer", "--obj=" + elf, "--inlines", "--functions=short"],
+                             input="\n".join(hex(a) for a, _ in insts) + "\n", capture_output=True, text=True, check=True).stdout
+        stacks = [blk.strip().split("\n") for blk in sym.strip().split("\n\n")]
+        total = cold = 0
+        for (addr, mn), st in zip(insts, stacks):
+            loc = st[1] if len(st) > 1 else ""
+            f, l = (loc.rsplit(":", 2) + ["0", "0"])[0:2]
+            is_cold = f.endswith("device_math.hpp") and int(l) in cold_lines()
+            if is_cold:
+                cold += slots(mn)
+            else:
+                total += slots(mn)
+        out[name] = (total, cold)
+    base = out.pop("empty")[0]
+    return {k: {"slots": v[0] - base, "cold_fallback_slots": v[1]} for k, v in out.items()}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--flags", type=int, default=0, help="kernel variant: 1 stats, 2 sunlight, 4 alpha, 8 hbm-scene")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--slots-json", default=None, help="write the per-operation VALU issue slots of every production variant (0, 2, 4, 6, 8, 10, 12, 14)")
     args = ap.parse_args()
+    if args.slots_json:
+        probes = probe_slots()
+        t = {"_doc": ("VALU issue slots (1 = 2 SIMD cycles; fma / mad 2, rcp / sqrt 4) of ONE call of each reference operation: the kernels of "
+                      "tools/probes/isa_probes.hip (the same device_math.hpp / device_access.hpp functions the tracing kernel inlines), compiled with the "
+                      "Makefile's flags, disassembled and counted by tools/isa_by_phase.py; the empty probe is subtracted, the out-of-range fallbacks of "
+                      "exact_rcp / exact_sqrt are listed apart.  bench.py: algorithmic_frac = sum(work counter x slots) / 64 lanes / kernel time / peak. "
+                      "in_kernel: the same helpers as inlined in path_pool_kernel<0> (static slots of all their inlined copies, fallbacks included) for comparison."),
+             "per_call": probes}
+        table, n = census(0)
+        t["in_kernel"] = {"%s/%s" % (ph, op): {"slots": c["slots"], "source_call_sites": c["copies"]} for (ph, op), c in sorted(table.items())
+                          if op in ("tri_intersect_flat", "slab_entry_or_inf", "random_unit_sphere_try", "closest_hit_frame", "make_ray", "camera_get_ray")}
+        with open(args.slots_json, "w") as f:
+            json.dump(t, f, indent=1)
+        for k, v in probes.items():
+            print("%-16s %s" % (k, v))
+        return
     table, n = census(args.flags)
     cols = ["valu", "lane", "slots", "salu", "lds", "vmem", "smem", "wait", "branch"]
     print("path_pool_kernel<%d>: %d instructions (static)" % (args.flags, n))

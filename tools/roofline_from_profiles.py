@@ -78,6 +78,24 @@ def derive(c, kernel_s):
         d["valu_issue_frac"] = slots / kernel_s / (SIMDS * CLOCK_HZ / 2)
     if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_THREAD_CYCLES_VALU"):
         d["lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
+    if c.get("SQ_WAVE_CYCLES"):
+        # where a resident wave's cycles go (MI355X_MICROARCH.md "SQ": WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES, disjoint)
+        w = c["SQ_WAVE_CYCLES"]
+        d["wave_time"] = {k: round(c[n] / w, 4) for k, n in (("parked_at_waitcnt", "SQ_WAIT_ANY"), ("issue_stalled", "SQ_WAIT_INST_ANY"),
+                                                            ("issuing_any", "SQ_ACTIVE_INST_ANY"), ("issuing_scalar", "SQ_ACTIVE_INST_SCA"),
+                                                            ("issuing_lds", "SQ_ACTIVE_INST_LDS")) if c.get(n) is not None}
+        if c.get("SQ_ACTIVE_INST_VALU"):
+            d["wave_time"]["issuing_valu"] = round(c["SQ_ACTIVE_INST_VALU"] / w, 4)
+    if c.get("TCC_REQ_sum"):
+        # L2 (MI355X_MICROARCH.md "L2": ~34.5 TB/s aggregate; a request moves at most one 128-byte line)
+        req, hit, miss = c["TCC_REQ_sum"], c.get("TCC_HIT_sum", 0.0), c.get("TCC_MISS_sum", 0.0)
+        d["l2"] = {"requests_per_launch": int(req), "hit_rate": round(hit / max(hit + miss, 1.0), 4),
+                   "requests_per_s": req / kernel_s, "bandwidth_frac_upper_bound": round(req * 128.0 / kernel_s / 34.5e12, 4),
+                   "note": "requests x 128 B / kernel time / 34.5 TB/s: an UPPER bound of the L2 bandwidth in use (most requests of this kernel are 16- to 64-byte gathers)"}
+    if c.get("SQ_INSTS_VMEM_RD") and c.get("SQ_INSTS_VALU"):
+        d["valu_per_vector_memory_read"] = round(c["SQ_INSTS_VALU"] / c["SQ_INSTS_VMEM_RD"], 1)
+    if c.get("SQ_LDS_IDX_ACTIVE"):
+        d["lds_bank_conflict_share_of_lds_cycles"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
     if c.get("GRBM_GUI_ACTIVE"):
         d["shader_clock_ghz_during_kernel"] = c["GRBM_GUI_ACTIVE"] / 8.0 / kernel_s / 1e9      # the counter sums the 8 XCDs
     return d
