@@ -661,6 +661,9 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
         n_frames = std::min<uint32_t>(n_frames, (uint32_t)r->settings.max_samples - r->frame_index);
     if (n_frames == 0) return DRT_OK;
     HIP_TRY(hipSetDevice(r->device));
+    // hipGetLastError() after a launch reports the last error of ANY earlier runtime call of this thread -- also one that another
+    // library made and handled (RCCL probing peers answers "invalid device ordinal" on a one-GPU box): start from a clean slate
+    (void)hipGetLastError();
     int rc = upload_scene(r, scene);
     if (rc != DRT_OK) return rc;
     if (r->bvh_depth > 64) return fail(DRT_ERR_UNSUPPORTED, "BVH deeper than 64 levels (the reference's traversal stack, BVHTraversal.cuh:17)");
@@ -902,6 +905,7 @@ int drt_assemble_shards(const void *gathered, void *image, uint32_t width, uint3
                         uint32_t world, uint32_t padded_rows, void *hip_stream) {
     if (!gathered || !image || stripe_rows == 0 || world == 0) return fail(DRT_ERR_INVALID, "bad argument");
     if (padded_rows < drt_shard_rows(height, stripe_rows, 0, world)) return fail(DRT_ERR_INVALID, "padded_rows smaller than rank 0's shard");
+    (void)hipGetLastError();                 // (see render_batch_impl: only this launch's own error counts)
     HIP_TRY(launch_assemble(gathered, image, width, height, stripe_rows, world, padded_rows, (hipStream_t)hip_stream));
     return DRT_OK;
 }

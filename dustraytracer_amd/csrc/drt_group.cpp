@@ -2,10 +2,15 @@
 //
 // One process, N devices (SURVEY.md 5 "Distributed communication backend", 8(e)): a renderer per device renders its
 // framebuffer stripes (drt_renderer_set_shard: 8-row stripes dealt round robin, RNG seeds from the global pixel index, so
-// the assembled image is bit-identical to the one-GPU image), then the stripes are gathered into device 0's image over
-// RCCL: one grouped batch of ncclSend / ncclRecv per frame, every stripe received AT ITS PLACE in the full image (the
-// receive offsets de-interleave; there is no assemble pass), each peer on its own xGMI link into device 0.  Nothing else
-// is exchanged: the path has no data-path collective.
+// the assembled image is bit-identical to the one-GPU image), then the shards are gathered on device 0 over RCCL: ONE
+// ncclSend / ncclRecv pair per peer and frame -- a peer's shard is contiguous in its own buffer -- into a staging buffer on
+// device 0 ([rank][row of the shard]; device 0's renderer renders straight into its slot), each peer on its own xGMI link,
+// then ONE kernel de-interleaves the stripes into the full image (drt_assemble_shards).  Nothing else is exchanged: the path
+// has no data-path collective.  (Round 2 received every 8-row stripe at its rows of the image: no assemble pass, but 118
+// send / receive pairs per 1080p frame on the critical path of a 0.4 ms step; DRT_GROUP_GATHER=stripes still does that, for
+// timing the two against each other.)
+// MORE THAN ONE DEVICE HAS NEVER RUN HERE (one-GPU boxes): what is tested is the address arithmetic (CPU), a group of one, and
+// the RCCL plumbing with the one device sending to itself (DRT_GROUP_FORCE_RCCL).
 // RCCL is loaded at run time (dlopen "librccl.so.1") when a group of more than one device is created: the library
 // has no link-time dependency on it, and a process that already carries another copy (PyTorch ships its own) is not
 // handed a second one unless it asks for a group.
@@ -66,9 +71,13 @@ struct drt_group {
     std::vector<hipStream_t> streams;
     std::vector<void *> comms;                // RCCL communicators, one per device (empty for a group of one)
     float *image = nullptr;                   // device 0: the full RGBA32F frame, rows in place
+    float *staging = nullptr;                 // device 0: [rank][padded_rows][width] RGBA32F -- the shards as the ranks hold them (slot 0 = device 0's own render target)
+    float *accum0 = nullptr;                  // device 0: its renderer's accumulation buffer (bound together with staging slot 0)
+    uint32_t padded_rows = 0;                 // rows of the largest shard (rank 0's)
     uint32_t width = 0, height = 0;
     bool pending = false;
     bool self_gather = false;                 // DRT_GROUP_FORCE_RCCL: device 0's own stripes go through RCCL too
+    bool per_stripe = false;                  // DRT_GROUP_GATHER=stripes: round 2's gather (a send / receive pair per stripe, received in place)
     std::chrono::steady_clock::time_point t0;
 };
 
@@ -125,6 +134,7 @@ drt_group *drt_group_create(const int32_t *devices, int32_t n_devices) {
     // DRT_GROUP_FORCE_RCCL=1: a group of ONE device also creates its communicator and gathers its stripes through
     // ncclSend / ncclRecv to itself -- the RCCL plumbing can then be exercised on a one-GPU box
     g->self_gather = n_devices == 1 && std::getenv("DRT_GROUP_FORCE_RCCL") && std::atoi(std::getenv("DRT_GROUP_FORCE_RCCL")) != 0;
+    g->per_stripe = std::getenv("DRT_GROUP_GATHER") && std::strcmp(std::getenv("DRT_GROUP_GATHER"), "stripes") == 0;
     if (n_devices > 1 || g->self_gather) {
         const std::string err = g_rccl.load();
         if (!err.empty()) { drt_internal_fail(DRT_ERR_DEVICE, err.c_str()); drt_group_destroy(g); return nullptr; }
@@ -142,10 +152,15 @@ drt_group *drt_group_create(const int32_t *devices, int32_t n_devices) {
 
 void drt_group_destroy(drt_group *g) {
     if (!g) return;
+    if (g->pending) (void)drt_group_wait(g, nullptr);      // sends / receives may still target what is freed below
+    for (size_t i = 0; i < g->streams.size(); i++) if (hipSetDevice(g->devices[i]) == hipSuccess) (void)hipStreamSynchronize(g->streams[i]);
     for (void *c : g->comms) if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
     for (size_t i = 0; i < g->renderers.size(); i++) drt_renderer_destroy(g->renderers[i]);
     for (size_t i = 0; i < g->streams.size(); i++) { (void)hipSetDevice(g->devices[i]); (void)hipStreamDestroy(g->streams[i]); }
-    if (g->image) { (void)hipSetDevice(g->devices[0]); (void)hipFree(g->image); }
+    if (!g->devices.empty()) (void)hipSetDevice(g->devices[0]);
+    if (g->image) (void)hipFree(g->image);
+    if (g->staging) (void)hipFree(g->staging);
+    if (g->accum0) (void)hipFree(g->accum0);
     delete g;
 }
 
@@ -158,18 +173,32 @@ void *drt_group_device_rgba(drt_group *g) { return g ? g->image : nullptr; }
 
 int drt_group_resize(drt_group *g, uint32_t width, uint32_t height) {
     if (!g) return drt_internal_fail(DRT_ERR_INVALID, "null group");
+    if (width == g->width && height == g->height && g->image) return DRT_OK;          // Renderer.cu:29-31: same size, nothing happens
+    if (g->pending) { const int rc = drt_group_wait(g, nullptr); if (rc != DRT_OK) return rc; }     // nothing in flight may target what is reallocated
+    GROUP_HIP(hipSetDevice(g->devices[0]));
+    { const int rc = drt_renderer_bind_buffers(g->renderers[0], nullptr, nullptr); if (rc != DRT_OK) return rc; }
     for (drt_renderer *r : g->renderers) {
         const int rc = drt_renderer_resize(r, width, height);
         if (rc != DRT_OK) return rc;
     }
-    if (width != g->width || height != g->height || !g->image) {
-        GROUP_HIP(hipSetDevice(g->devices[0]));
-        if (g->image) { (void)hipFree(g->image); g->image = nullptr; }
-        GROUP_HIP(hipMalloc((void **)&g->image, std::max<size_t>((size_t)width * height, 1) * 4 * sizeof(float)));
-        GROUP_HIP(hipMemset(g->image, 0, std::max<size_t>((size_t)width * height, 1) * 4 * sizeof(float)));
-        g->width = width; g->height = height;
-    }
-    return DRT_OK;
+    GROUP_HIP(hipSetDevice(g->devices[0]));
+    if (g->image) { (void)hipFree(g->image); g->image = nullptr; }
+    if (g->staging) { (void)hipFree(g->staging); g->staging = nullptr; }
+    if (g->accum0) { (void)hipFree(g->accum0); g->accum0 = nullptr; }
+    const uint32_t world = (uint32_t)g->renderers.size();
+    g->padded_rows = drt_shard_rows(height, kStripeRows, 0, world);
+    const size_t image_floats = std::max<size_t>((size_t)width * height, 1) * 4;
+    const size_t shard_floats = std::max<size_t>((size_t)width * g->padded_rows, 1) * 4;
+    GROUP_HIP(hipMalloc((void **)&g->image, image_floats * sizeof(float)));
+    GROUP_HIP(hipMemset(g->image, 0, image_floats * sizeof(float)));
+    const size_t slots = world + (g->self_gather ? 1u : 0u);           // (self-gather: one more slot, for the one device to receive its own shard in)
+    GROUP_HIP(hipMalloc((void **)&g->staging, shard_floats * slots * sizeof(float)));
+    GROUP_HIP(hipMemset(g->staging, 0, shard_floats * slots * sizeof(float)));
+    GROUP_HIP(hipMalloc((void **)&g->accum0, shard_floats / 4 * 3 * sizeof(float)));
+    g->width = width; g->height = height;
+    // device 0 renders straight into slot 0 of the staging buffer: its shard needs no copy before the assemble pass
+    { const int rc = drt_renderer_bind_buffers(g->renderers[0], g->accum0, g->staging); if (rc != DRT_OK) return rc; }
+    return drt_renderer_reset(g->renderers[0]);
 }
 
 int drt_group_set_settings(drt_group *g, const drt_settings *s) {
@@ -191,39 +220,66 @@ int drt_group_render_batch_async(drt_group *g, const drt_camera *cam, const drt_
     if (g->width == 0 || g->height == 0) return drt_internal_fail(DRT_ERR_INVALID, "drt_group_resize has not been called");
     const uint32_t world = (uint32_t)g->renderers.size();
     g->t0 = std::chrono::steady_clock::now();
+    // From here on work may be in flight on any device: whatever goes wrong below, the group is drained before the error is
+    // returned (drt_group_wait; an open RCCL group is closed first), so that the caller may destroy or resize it safely.
+    g->pending = true;
+    int rc = DRT_OK;
+    bool in_rccl_group = false;
+    auto hip_ok = [&](hipError_t e, const char *what) { if (e != hipSuccess && rc == DRT_OK) rc = drt_internal_fail(DRT_ERR_DEVICE, (std::string(what) + ": " + hipGetErrorString(e)).c_str()); return e == hipSuccess; };
+    auto nccl_ok = [&](int e, const char *what) { if (e != 0 && rc == DRT_OK) rc = drt_internal_fail(DRT_ERR_DEVICE, (std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "RCCL error")).c_str()); return e == 0; };
     for (drt_renderer *r : g->renderers) {                 // every device starts tracing before anything is gathered
-        const int rc = drt_renderer_render_batch_async(r, cam, scene, n_frames);
-        if (rc != DRT_OK) return rc;
+        rc = drt_renderer_render_batch_async(r, cam, scene, n_frames);
+        if (rc != DRT_OK) break;
     }
-    // device 0's own stripes: one strided copy on its stream (behind its render): local stripe k -> image stripe k * world
-    if (!g->self_gather) {
-        GROUP_HIP(hipSetDevice(g->devices[0]));
-        const size_t stripe_bytes = (size_t)kStripeRows * g->width * 4 * sizeof(float);
-        const uint32_t local_rows = drt_renderer_local_rows(g->renderers[0]);
-        const uint32_t full = local_rows / kStripeRows, rest = local_rows % kStripeRows;
-        const float *src = static_cast<const float *>(drt_renderer_device_rgba(g->renderers[0]));
-        if (full) GROUP_HIP(hipMemcpy2DAsync(g->image, stripe_bytes * world, src, stripe_bytes, stripe_bytes, full, hipMemcpyDeviceToDevice, g->streams[0]));
-        if (rest) {
+    const size_t shard_floats = (size_t)g->width * g->padded_rows * 4;
+    if (rc == DRT_OK && g->per_stripe) {
+        // ---- round 2's gather: every stripe received at its rows of the image ----
+        // device 0's own stripes: one strided copy on its stream (behind its render): local stripe k -> image stripe k * world
+        if (!g->self_gather && hip_ok(hipSetDevice(g->devices[0]), "hipSetDevice")) {
+            const size_t stripe_bytes = (size_t)kStripeRows * g->width * 4 * sizeof(float);
+            const uint32_t local_rows = drt_renderer_local_rows(g->renderers[0]);
+            const uint32_t full = local_rows / kStripeRows, rest = local_rows % kStripeRows;
+            const float *src = static_cast<const float *>(drt_renderer_device_rgba(g->renderers[0]));
+            if (full) hip_ok(hipMemcpy2DAsync(g->image, stripe_bytes * world, src, stripe_bytes, stripe_bytes, full, hipMemcpyDeviceToDevice, g->streams[0]), "hipMemcpy2DAsync");
             uint64_t so, dof, cnt;
-            if (drt_shard_stripe(g->width, g->height, kStripeRows, 0, world, full, &so, &dof, &cnt))
-                GROUP_HIP(hipMemcpyAsync(g->image + dof, src + so, cnt * sizeof(float), hipMemcpyDeviceToDevice, g->streams[0]));
+            if (rest && drt_shard_stripe(g->width, g->height, kStripeRows, 0, world, full, &so, &dof, &cnt))
+                hip_ok(hipMemcpyAsync(g->image + dof, src + so, cnt * sizeof(float), hipMemcpyDeviceToDevice, g->streams[0]), "hipMemcpyAsync");
         }
-    }
-    if (world > 1 || g->self_gather) {
-        // one group: every peer sends each of its stripes to device 0, which receives it at its rows of the full image
-        GROUP_NCCL(g_rccl.GroupStart());
-        for (uint32_t rank = g->self_gather ? 0 : 1; rank < world; rank++) {
-            const float *src = static_cast<const float *>(drt_renderer_device_rgba(g->renderers[rank]));
-            for (uint32_t k = 0;; k++) {
-                uint64_t so, dof, cnt;
-                if (!drt_shard_stripe(g->width, g->height, kStripeRows, rank, world, k, &so, &dof, &cnt)) break;
-                GROUP_NCCL(g_rccl.Send(src + so, (size_t)cnt, Rccl::kFloat, 0, g->comms[rank], g->streams[rank]));
-                GROUP_NCCL(g_rccl.Recv(g->image + dof, (size_t)cnt, Rccl::kFloat, (int)rank, g->comms[0], g->streams[0]));
+        if (rc == DRT_OK && (world > 1 || g->self_gather) && nccl_ok(g_rccl.GroupStart(), "ncclGroupStart")) {
+            in_rccl_group = true;
+            for (uint32_t rank = g->self_gather ? 0 : 1; rank < world && rc == DRT_OK; rank++) {
+                const float *src = static_cast<const float *>(drt_renderer_device_rgba(g->renderers[rank]));
+                for (uint32_t k = 0; rc == DRT_OK; k++) {
+                    uint64_t so, dof, cnt;
+                    if (!drt_shard_stripe(g->width, g->height, kStripeRows, rank, world, k, &so, &dof, &cnt)) break;
+                    if (nccl_ok(g_rccl.Send(src + so, (size_t)cnt, Rccl::kFloat, 0, g->comms[rank], g->streams[rank]), "ncclSend"))
+                        nccl_ok(g_rccl.Recv(g->image + dof, (size_t)cnt, Rccl::kFloat, (int)rank, g->comms[0], g->streams[0]), "ncclRecv");
+                }
             }
         }
-        GROUP_NCCL(g_rccl.GroupEnd());
+    } else if (rc == DRT_OK) {
+        // ---- one transfer per peer: its whole shard (contiguous where it was rendered) into its slot of the staging buffer ----
+        if ((world > 1 || g->self_gather) && nccl_ok(g_rccl.GroupStart(), "ncclGroupStart")) {
+            in_rccl_group = true;
+            for (uint32_t rank = g->self_gather ? 0 : 1; rank < world && rc == DRT_OK; rank++) {
+                const float *src = static_cast<const float *>(drt_renderer_device_rgba(g->renderers[rank]));
+                const size_t count = (size_t)g->width * drt_renderer_local_rows(g->renderers[rank]) * 4;
+                // (the self-gather of a one-device group: slot 0, where the device rendered, is sent to slot 1, and the assemble pass
+                // below reads slot 1 -- the image then really is what RCCL moved)
+                float *dst = g->staging + (size_t)(g->self_gather ? 1u : rank) * shard_floats;
+                if (count == 0) continue;
+                if (nccl_ok(g_rccl.Send(src, count, Rccl::kFloat, 0, g->comms[rank], g->streams[rank]), "ncclSend"))
+                    nccl_ok(g_rccl.Recv(dst, count, Rccl::kFloat, (int)rank, g->comms[0], g->streams[0]), "ncclRecv");
+            }
+        }
     }
-    g->pending = true;
+    if (in_rccl_group) nccl_ok(g_rccl.GroupEnd(), "ncclGroupEnd");          // (also on the error path: never leave the thread inside an open group)
+    if (rc == DRT_OK && !g->per_stripe) {
+        // the stripes of every shard to their rows of the image: one kernel on device 0's stream, behind its render and the receives
+        if (hip_ok(hipSetDevice(g->devices[0]), "hipSetDevice"))
+            rc = drt_assemble_shards(g->staging + (g->self_gather ? shard_floats : 0u), g->image, g->width, g->height, kStripeRows, world, g->padded_rows, g->streams[0]);
+    }
+    if (rc != DRT_OK) { (void)drt_group_wait(g, nullptr); return rc; }
     return DRT_OK;
 }
 

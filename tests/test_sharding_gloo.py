@@ -132,24 +132,56 @@ def test_group_of_one_device_equals_the_single_renderer():
         d.RendererGroup([97])
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("W,H", [(64, 44), (7, 8), (16, 129)])
+def test_group_gather_of_whole_shards_rebuilds_the_image(world, W, H):
+    """The gather of drt_group_render_batch (csrc/drt_group.cpp, round 3): every peer's shard goes, whole and contiguous, to its
+    slot [rank][padded_rows][W] of a staging buffer on device 0, and one pass copies row y of the image from slot
+    (y / 8) % world, shard row (y / 8 / world) * 8 + y % 8 (drt_assemble_shards).  CPU statement of that bookkeeping for worlds
+    2, 3 and 8, short last stripe included: the count sent is the shard's size, slots do not overlap, the image is rebuilt."""
+    from dustraytracer_amd.sharding import shard_row_map
+    rng = np.random.default_rng(W * 977 + H + world)
+    image = rng.random((H, W, 4), dtype=np.float32)
+    padded = drt.shard_rows(H, STRIPE, 0, world)
+    staging = np.full((world, padded, W, 4), np.nan, np.float32)
+    for rank in range(world):
+        rows = shard_row_map(H, STRIPE, rank, world)
+        n = drt.shard_rows(H, STRIPE, rank, world)
+        assert n == len(rows) <= padded
+        staging[rank].reshape(-1)[:n * W * 4] = image[rows].reshape(-1)     # ONE contiguous transfer of n * W * 4 floats
+    rebuilt = np.empty_like(image)
+    for y in range(H):
+        s = y // STRIPE
+        rebuilt[y] = staging[s % world, (s // world) * STRIPE + y % STRIPE]
+    assert np.array_equal(bits(rebuilt), bits(image))
+
+
 @pytest.mark.gpu
-def test_group_gather_through_rccl_on_one_device(monkeypatch):
-    """DRT_GROUP_FORCE_RCCL=1: the group of one device loads RCCL (dlopen), creates its communicator and moves its stripes with
-    grouped ncclSend / ncclRecv (to itself) at the offsets of drt_shard_stripe -- the plumbing of the N-GPU gather, on this box."""
+@pytest.mark.parametrize("gather", ["shards", "stripes"])
+def test_group_gather_through_rccl_on_one_device(monkeypatch, gather):
+    """DRT_GROUP_FORCE_RCCL=1: the group of one device loads RCCL (dlopen), creates its communicator and moves its shard with
+    ncclSend / ncclRecv to itself -- whole, into a second staging slot that the assemble pass then reads (the default), or stripe
+    by stripe at the offsets of drt_shard_stripe (DRT_GROUP_GATHER=stripes, round 2's gather) -- the plumbing of the N-GPU
+    gather, on this box.  More than one device has never run here."""
     import dustraytracer_amd as d
     monkeypatch.setenv("DRT_GROUP_FORCE_RCCL", "1")
+    monkeypatch.setenv("DRT_GROUP_GATHER", gather)
     try:
         g = d.RendererGroup([0])
     except d.DrtError as e:
         pytest.skip("RCCL cannot be loaded here: %s" % e)
     monkeypatch.delenv("DRT_GROUP_FORCE_RCCL")
+    monkeypatch.delenv("DRT_GROUP_GATHER")
     r = d.Renderer(0)
     sc = d.Scene(); sc.loadGLTFmodel(scene_path("room"))
     b = d.BVHBuilder(); b.m_TargetLeafPrimitivesCount, b.m_BinCount = 20, 8; b.buildIterative(sc)
     _, pos, fwd, _ = SCENES["room"]
     cam = d.Camera(pos); cam.m_Forward_dir = np.array(fwd, np.float32)
-    for x in (g, r):
-        x.m_RendererSettings = d.RendererSettings(ray_bounce_limit=3, max_samples=100)
-        x.ResizeBuffer(200, 61)                                          # 7 full stripes + one of 5 rows
-        x.RenderBatch(cam, sc, 2)
-    assert np.array_equal(bits(g.GetRenderTargetImage()), bits(r.GetRenderTargetImage()))
+    for size in ((200, 61), (96, 40)):                                   # 7 full stripes + one of 5 rows; then a resize with work done before
+        for x in (g, r):
+            x.m_RendererSettings = d.RendererSettings(ray_bounce_limit=3, max_samples=100)
+            x.ResizeBuffer(*size)
+            x.RenderBatch(cam, sc, 2)
+        assert np.array_equal(bits(g.GetRenderTargetImage()), bits(r.GetRenderTargetImage()))
+        g.RenderBatchAsync(cam, sc, 1); r.RenderBatch(cam, sc, 1)        # left in flight: the next resize (or the destructor) drains it
+    del g
