@@ -89,8 +89,14 @@ struct drt_renderer {
     bool pending = false;                     // an asynchronous render was enqueued and not waited for yet
     unsigned long long *counters = nullptr;
     static constexpr int kMaxSpans = 64;
-    unsigned long long *spans = nullptr;      // kMaxSpans x {max(~start), max(end)}: execution span of each wave_queue launch of the last batch
-    int spans_used = 0;
+    // One 32-byte record per tracing-kernel launch: {max(~first wave in), max(last wave out), status bits, -}.  The records come
+    // zeroed from a ring (one memset per kRecords launches); those of a batch are copied to pinned host memory on the stream, in
+    // front of ev_stop, so that drt_renderer_wait reads spans and status without another trip to the device.
+    static constexpr int kRecords = 1024;
+    unsigned long long *records = nullptr;    // device: kRecords x 4 words
+    unsigned long long *records_host = nullptr;   // pinned: the kMaxSpans records of the last batch
+    int records_used = 0, batch_first_record = 0;
+    int spans_used = 0;                       // launches of the last batch that have a record
     int launches_last = 0;                     // tracing-kernel launches of the last batch (a batch is split by the sample budget)
     float span_ms = 0.f;                       // sum of those spans, filled by drt_renderer_wait
     int wall_clock_khz = 100000;
@@ -104,8 +110,6 @@ struct drt_renderer {
     int frames_in_flight = 1;                 // drt_renderer_set_frames_in_flight
     bool use_pixel_walk = false;              // DRT_KERNEL=pixel_walk selects the first (non-persistent) kernel
     int use_path_pool = 1;                    // path_pool where it applies (lean paths, scene in LDS); DRT_KERNEL=wave_queue: never
-    unsigned int *pool_status = nullptr;      // device word: set by an aborted path_pool launch
-    unsigned int *pool_status_host = nullptr; // pinned host word: the device word as of the end of the last batch (copied on the stream, before ev_stop)
     bool pool_launched = false;               // the batch in flight launched path_pool at least once
     WaveQueueCache wq_cache;                  // measured choice among wave_queue's launch packagings
     PoolScratch pool_scratch;
@@ -348,6 +352,11 @@ drt_renderer *drt_renderer_create(int32_t device) {
     drt_default_settings(&r->settings);
     const char *which = std::getenv("DRT_KERNEL");
     r->use_pixel_walk = which && std::strcmp(which, "pixel_walk") == 0;
+    if (r->use_pixel_walk && !pixel_walk_built_in()) {
+        fail(DRT_ERR_UNSUPPORTED, "DRT_KERNEL=pixel_walk: that kernel is not part of this library (the tests build libdrt_hip_pixel_walk.so: make pixel-walk)");
+        delete r;
+        return nullptr;
+    }
     r->use_path_pool = !(which && (std::strcmp(which, "wave_queue") == 0 || std::strcmp(which, "pixel_walk") == 0));
     auto env_int = [](const char *name, int dflt) { const char *v = std::getenv(name); return (v && *v) ? std::atoi(v) : dflt; };
     r->vote_node = std::max(1, env_int("DRT_VOTE_N", r->vote_node));
@@ -376,12 +385,12 @@ drt_renderer *drt_renderer_create(int32_t device) {
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) r->wall_clock_khz = khz;
     if (hipEventCreate(&r->ev_start) != hipSuccess || hipEventCreate(&r->ev_stop) != hipSuccess ||
         hipMalloc((void **)&r->counters, sizeof(drt_counters)) != hipSuccess ||
-        hipMalloc((void **)&r->spans, sizeof(unsigned long long) * 2 * drt_renderer::kMaxSpans) != hipSuccess ||
+        hipMalloc((void **)&r->records, sizeof(unsigned long long) * 4 * drt_renderer::kRecords) != hipSuccess ||
+        hipMemset(r->records, 0, sizeof(unsigned long long) * 4 * drt_renderer::kRecords) != hipSuccess ||
+        hipHostMalloc((void **)&r->records_host, sizeof(unsigned long long) * 4 * drt_renderer::kMaxSpans, hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void **)&r->tile_counter, sizeof(unsigned int) * drt_renderer::kCounters * kQueueHeadBlockWords) != hipSuccess ||
         hipMemset(r->tile_counter, 0, sizeof(unsigned int) * drt_renderer::kCounters * kQueueHeadBlockWords) != hipSuccess ||
-        hipMalloc((void **)&r->pool_status, sizeof(unsigned int)) != hipSuccess ||
-        hipMemset(r->pool_status, 0, sizeof(unsigned int)) != hipSuccess ||
-        hipHostMalloc((void **)&r->pool_status_host, sizeof(unsigned int), hipHostMallocDefault) != hipSuccess) {
+        false) {
         fail(DRT_ERR_DEVICE, "cannot create HIP events / counter buffer");
         drt_renderer_destroy(r);
         return nullptr;
@@ -396,10 +405,9 @@ void drt_renderer_destroy(drt_renderer *r) {
     if (r->accum) (void)hipFree(r->accum);
     if (r->rgba) (void)hipFree(r->rgba);
     if (r->counters) (void)hipFree(r->counters);
-    if (r->spans) (void)hipFree(r->spans);
+    if (r->records) (void)hipFree(r->records);
+    if (r->records_host) (void)hipHostFree(r->records_host);
     if (r->tile_counter) (void)hipFree(r->tile_counter);
-    if (r->pool_status) (void)hipFree(r->pool_status);
-    if (r->pool_status_host) (void)hipHostFree(r->pool_status_host);
     if (r->pool_tuning.stats) (void)hipFree(r->pool_tuning.stats);
     if (r->pool_scratch.aux) (void)hipFree(r->pool_scratch.aux);
     if (r->pool_scratch.aux_slot) (void)hipFree(r->pool_scratch.aux_slot);
@@ -675,6 +683,7 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
     fp.n_frames = n_frames;
     if (r->counting) HIP_TRY(hipMemsetAsync(r->counters, 0, sizeof(drt_counters), r->stream));
 
+    r->spans_used = 0;
     HIP_TRY(hipEventRecord(r->ev_start, r->stream));                   // Renderer.cu:97
     const bool material_ext = fp.ext_emissive || fp.ext_specular;          // only the general wave_queue kernel implements it
     if (r->use_pixel_walk && !material_ext) {
@@ -692,11 +701,18 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
         }
         r->spans_used = 0;
         r->launches_last = 0;
-        HIP_TRY(hipMemsetAsync(r->spans, 0, sizeof(unsigned long long) * 2 * drt_renderer::kMaxSpans, r->stream));
+        if (r->records_used + drt_renderer::kMaxSpans > drt_renderer::kRecords) {      // stream order: every launch that used them is over by then
+            HIP_TRY(hipMemsetAsync(r->records, 0, sizeof(unsigned long long) * 4 * drt_renderer::kRecords, r->stream));
+            r->records_used = 0;
+        }
+        r->batch_first_record = r->records_used;
         for (uint32_t done = 0; done < n_frames; done += frames_per_launch) {
             fp.frame_first = r->frame_index + done;
             fp.n_frames = std::min(frames_per_launch, n_frames - done);
-            fp.span = r->spans_used < drt_renderer::kMaxSpans ? r->spans + 2 * r->spans_used++ : nullptr;
+            unsigned long long *const record = r->spans_used < drt_renderer::kMaxSpans ? r->records + 4 * (size_t)(r->batch_first_record + r->spans_used++) : nullptr;
+            if (record) r->records_used++;
+            fp.span = record;
+            unsigned int *const launch_status = record ? reinterpret_cast<unsigned int *>(record + 2) : nullptr;     // (beyond kMaxSpans launches per batch: no status word, the kernel still aborts cleanly)
             r->launches_last++;
             if (r->counters_used == drt_renderer::kCounters) {      // stream order: every launch that used them is over by then
                 HIP_TRY(hipMemsetAsync(r->tile_counter, 0, sizeof(unsigned int) * drt_renderer::kCounters * kQueueHeadBlockWords, r->stream));
@@ -706,16 +722,17 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
             bool pool_hbm_scene = false;
             if (r->use_path_pool && !material_ext &&
                 path_pool_supports(r->view, fp, r->bvh_depth, wave_queue_scene_lds_bytes(r->view), &pool_hbm_scene) && (r->pool_launched = true))
-                HIP_TRY(launch_path_pool(r->view, fp, r->bvh_depth, r->scene_has_alpha, pool_hbm_scene, r->pool_t_class, r->pool_tuning, r->pool_scratch, queue_head, r->samples, r->pool_status,
+                HIP_TRY(launch_path_pool(r->view, fp, r->bvh_depth, r->scene_has_alpha, pool_hbm_scene, r->pool_t_class, r->pool_tuning, r->pool_scratch, queue_head, r->samples, launch_status,
                                          r->num_cus, r->stream, &r->kernel_name, r->launch_shape));
             else
             HIP_TRY(launch_wave_queue(r->view, fp, r->bvh_depth, r->counting ? 2 : (material_ext ? 1 : 0), r->scene_has_alpha, queue_head,
                                       r->samples, r->num_cus, r->stream, &r->kernel_name, r->launch_shape, r->wq_cache));
         }
     }
-    // the kernel's status word travels to pinned host memory on the stream: drt_renderer_wait reads it after the event, no
-    // second round trip to the device (a 1/8-shard step is 0.4 ms)
-    if (r->pool_launched) { HIP_TRY(hipMemcpyAsync(r->pool_status_host, r->pool_status, sizeof(unsigned int), hipMemcpyDeviceToHost, r->stream)); }
+    // the launches' records (execution span, status bits) travel to pinned host memory on the stream: drt_renderer_wait reads them
+    // after the event, no second round trip to the device (a 1/8-shard step is 0.4 ms)
+    if (r->spans_used > 0)
+        HIP_TRY(hipMemcpyAsync(r->records_host, r->records + 4 * (size_t)r->batch_first_record, sizeof(unsigned long long) * 4 * (size_t)r->spans_used, hipMemcpyDeviceToHost, r->stream));
     HIP_TRY(hipEventRecord(r->ev_stop, r->stream));                    // Renderer.cu:105
     r->frame_index += n_frames;                                        // Renderer.cu:116
     r->pending = true;
@@ -742,28 +759,26 @@ int drt_renderer_wait(drt_renderer *r, float *delta_ms) {
     HIP_TRY(hipEventElapsedTime(&ms, r->ev_start, r->ev_stop));
     if (delta_ms) *delta_ms = ms;
     r->span_ms = 0.f;
+    unsigned int status = 0;
     if (r->spans_used > 0) {
-        unsigned long long host[2 * drt_renderer::kMaxSpans];
-        HIP_TRY(hipMemcpy(host, r->spans, sizeof(unsigned long long) * 2 * (size_t)r->spans_used, hipMemcpyDeviceToHost));
+        const unsigned long long *host = r->records_host;          // (copied on the stream before ev_stop)
         double ticks = 0;
         for (int i = 0; i < r->spans_used; i++) {
-            const unsigned long long start = ~host[2 * i], end = host[2 * i + 1];
-            if (host[2 * i] != 0 && end > start) ticks += (double)(end - start);
+            const unsigned long long start = ~host[4 * i], end = host[4 * i + 1];
+            if (host[4 * i] != 0 && end > start) ticks += (double)(end - start);
+            status |= (unsigned int)host[4 * i + 2];
         }
         r->span_ms = (float)(ticks / (double)r->wall_clock_khz);
     }
     wave_queue_report(r->wq_cache, r->span_ms);
     r->pending = false;
     if (r->pool_launched) {
-        const unsigned int status = *r->pool_status_host;      // (copied on the stream before ev_stop)
         r->pool_launched = false;
-        if (status != 0) {
-            (void)hipMemset(r->pool_status, 0, sizeof status);
+        if (status != 0)
             return fail(DRT_ERR_DEVICE, "path_pool kernel: status " + std::to_string(status) + (status < 0x100u ? " (a queue wait exceeded its bound; the launch was abandoned)"
-                                                                                                     : " (bits 8..: an index out of range was caught and clamped -- 0x100 triangle, 0x200 node, 0x400 leaf, "
-                                                                                                       "0x800 / 0x1000 hit triangle, 0x2000 material, 0x4000 texture, 0x8000 sample slot, 0x10000 / 0x20000 stack level, "
-                                                                                                       "0x40000 path id from a queue, 0x80000 shading record)"));
-        }
+                                                                                                 : " (bits 8..: an index out of range was caught and clamped -- 0x100 triangle, 0x200 node, 0x400 leaf, "
+                                                                                                   "0x800 / 0x1000 hit triangle, 0x2000 material, 0x4000 texture, 0x8000 sample slot, 0x10000 / 0x20000 stack level, "
+                                                                                                   "0x40000 path id from a queue, 0x80000 shading record)"));
     }
     return DRT_OK;
 }

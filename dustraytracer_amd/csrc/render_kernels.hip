@@ -4,7 +4,11 @@
 // inlines: RayGen (Shaders/RayGen.cuh:63-172), TraceRay/RayTest (Kernel/TraceRay.cu:15-38),
 // traverseBVH/_raytest (BVH/BVHTraversal.cuh:14-134), Intersection, AnyHit, ClosestHit, Miss.
 //
-// Kernel "pixel_walk" (this file, first correct path):
+// What the shipped library keeps of this file: the device known-answer-test kernel and the rank-0 de-interleave pass.
+// Kernel "pixel_walk" (round 1's first correct path) is compiled only with -DDRT_WITH_PIXEL_WALK -- `make pixel-walk` builds
+// dustraytracer_amd/libdrt_hip_pixel_walk.so, which the tests load as a third, straightforward implementation to cross-check
+// the production kernels; libdrt_hip.so does not contain it (DRT_KERNEL=pixel_walk is refused there).
+// Kernel "pixel_walk":
 //   * one lane per pixel, 8x8 pixel tile per wave64, 4 tiles (32x8 pixels) per 256-thread workgroup
 //   * a lane keeps its pixel for all frames of a batch: the running sum lives in registers and the
 //     framebuffer is touched once per batch (12 B read + 12 B + 16 B written per pixel)
@@ -23,6 +27,7 @@ namespace drt {
 
 namespace {
 
+#ifdef DRT_WITH_PIXEL_WALK
 constexpr int kBlockThreads = 256;
 
 struct Counters {
@@ -243,6 +248,8 @@ __global__ __launch_bounds__(kBlockThreads) void pixel_walk_kernel(const SceneVi
     }
 }
 
+#endif  // DRT_WITH_PIXEL_WALK
+
 // Known-answer tests of the device leaf functions (drt_debug_kat): the inputs/outputs are the ones of
 // tests/golden/kat_ref.npz, which was produced by the reference's own compiled sources.
 __global__ __launch_bounds__(256) void kat_kernel(int which, const uint32_t *in, uint32_t *out, uint32_t n, const FrameParams fp) {
@@ -300,6 +307,7 @@ __global__ void assemble_shards_kernel(const float4 *gathered, float4 *image, ui
     image[(size_t)y * width + x] = gathered[((size_t)rank * padded_rows + ly) * width + x];
 }
 
+#ifdef DRT_WITH_PIXEL_WALK
 template <int STACK>
 hipError_t launch_stack(const SceneView &sc, const FrameParams &fp, bool count, hipStream_t stream) {
     dim3 grid((fp.width + 31) / 32, (fp.local_rows + 7) / 8), block(kBlockThreads);
@@ -308,8 +316,12 @@ hipError_t launch_stack(const SceneView &sc, const FrameParams &fp, bool count, 
     return hipGetLastError();
 }
 
+#endif
+
 }  // namespace
 
+#ifdef DRT_WITH_PIXEL_WALK
+bool pixel_walk_built_in() { return true; }
 hipError_t launch_render(const SceneView &sc, const FrameParams &fp, int bvh_depth, bool count, hipStream_t stream,
                          const char **kernel_name) {
     if (fp.width == 0 || fp.local_rows == 0 || fp.n_frames == 0) return hipSuccess;
@@ -320,6 +332,10 @@ hipError_t launch_render(const SceneView &sc, const FrameParams &fp, int bvh_dep
     if (bvh_depth <= 64) { if (kernel_name) *kernel_name = "pixel_walk<stack64>"; return launch_stack<64>(sc, fp, count, stream); }
     return hipErrorInvalidValue;     // the reference's own stack is 64 deep (BVHTraversal.cuh:17)
 }
+#else
+bool pixel_walk_built_in() { return false; }
+hipError_t launch_render(const SceneView &, const FrameParams &, int, bool, hipStream_t, const char **) { return hipErrorNotSupported; }
+#endif
 
 hipError_t launch_kat(int which, const void *d_in, void *d_out, uint32_t n, const FrameParams &fp, hipStream_t stream) {
     if (n == 0) return hipSuccess;

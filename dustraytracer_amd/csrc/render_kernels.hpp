@@ -10,6 +10,8 @@
 
 namespace drt {
 
+// pixel_walk: only in builds with -DDRT_WITH_PIXEL_WALK (`make pixel-walk`: the tests' cross-check library)
+bool pixel_walk_built_in();
 hipError_t launch_render(const SceneView &scene, const FrameParams &frame, int bvh_depth, bool count_work,
                          hipStream_t stream, const char **kernel_name);
 

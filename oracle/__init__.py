@@ -48,7 +48,7 @@ class SceneC(C.Structure):
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "samples", "rays", "node_visits", "inner_visits", "tri_tests", "hits_textured", "hits_flat",
-        "shadow_rays", "inner_visits_shadow", "tri_tests_shadow", "anyhit_alpha", "sphere_iters", "max_stack")]
+        "shadow_rays", "inner_visits_shadow", "tri_tests_shadow", "anyhit_alpha", "sphere_iters", "max_stack", "sphere_iters_traced")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

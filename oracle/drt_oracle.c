@@ -524,7 +524,9 @@ static f3 ray_gen(uint32_t x, uint32_t y, uint32_t max_x, uint32_t max_y, const 
                 light = add3(light, mul3(sf->suncol, throughput));
         }
 
+        const uint64_t iters_before = cnt ? cnt->sphere_iters : 0;
         f3 fuzz = random_unit_sphere_vec3(&seed, cnt ? &cnt->sphere_iters : NULL);
+        if (cnt && i < bounces) cnt->sphere_iters_traced += cnt->sphere_iters - iters_before;
         if (ext && sc->ext_specular && ext->metallic && !debug) {   /* opt-in: mirror lobe, fuzzed by the roughness */
             f3 v = normalize3(ray.dir);
             f3 refl = sub3(v, scale3(payload.normal, 2.0f * dot3(v, payload.normal)));
@@ -602,6 +604,7 @@ static void add_counters(o_counters *a, const o_counters *b)
     a->shadow_rays += b->shadow_rays; a->inner_visits_shadow += b->inner_visits_shadow;
     a->tri_tests_shadow += b->tri_tests_shadow; a->anyhit_alpha += b->anyhit_alpha;
     a->sphere_iters += b->sphere_iters;
+    a->sphere_iters_traced += b->sphere_iters_traced;
     if (b->max_stack > a->max_stack) a->max_stack = b->max_stack;
 }
 

@@ -123,6 +123,8 @@ typedef struct {
     uint64_t anyhit_alpha;     /* alpha texel fetches in AnyHit */
     uint64_t sphere_iters;     /* randomUnitSphereVec3 loop iterations */
     uint64_t max_stack;        /* max traversal stack height seen */
+    uint64_t sphere_iters_traced;   /* of sphere_iters: candidates of directions that a ray is then traced along (the reference also draws one
+                                       after the last bounce, RayGen.cuh:88,133-134: its ray is never traced and nothing reads the seed again) */
 } o_counters;
 
 void o_default_settings(o_settings *s);

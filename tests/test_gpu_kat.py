@@ -98,7 +98,33 @@ def test_rng_hash_has_short_cycles_and_the_guard_terminates():
     assert np.isfinite(vec[stuck]).all() and np.allclose(np.linalg.norm(vec[stuck].astype(np.float64), axis=1), 1.0, atol=1e-6)
 
 
-@pytest.mark.parametrize("kernel", ["path_pool", "wave_queue", "pixel_walk"])
+def test_pixel_walk_cross_check_library():
+    """Round 1's first kernel (one lane per pixel, nested loops) is no longer part of libdrt_hip.so; `make pixel-walk` builds
+    dustraytracer_amd/libdrt_hip_pixel_walk.so with it, and a child process loads THAT library and asks it the same two
+    questions as the production kernels: the hand-derived tie scene below, and a whole image against the oracle."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "dustraytracer_amd", "libdrt_hip_pixel_walk.so")
+    assert os.path.exists(lib), "build it: make -C dustraytracer_amd/csrc pixel-walk (__graft_entry__.build() does)"
+    with pytest.raises(drt.DrtError):                       # the shipped library refuses the name
+        from tests.test_gpu_parity import _renderer_with_env
+        _renderer_with_env({"DRT_KERNEL": "pixel_walk"})
+    env = dict(os.environ, DRT_LIB_OVERRIDE=lib, DRT_PIXEL_WALK_CHILD="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k", "pixel_walk_child"], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+@pytest.mark.skipif(__import__("os").environ.get("DRT_PIXEL_WALK_CHILD") != "1", reason="runs in the child process of test_pixel_walk_cross_check_library")
+def test_pixel_walk_child():
+    from tests.test_gpu_parity import _render_with_env, compare
+    test_equal_distances_and_equal_hits_resolve_as_in_the_reference_on_the_device("pixel_walk")
+    r, ref, _ = _render_with_env({"DRT_KERNEL": "pixel_walk"}, "suzanne_plane", 128, 72, 2, 2)
+    assert r.kernelInfo().startswith("pixel_walk")
+    compare(r.GetRenderTargetImage(), ref, "pixel_walk")
+
+
+@pytest.mark.parametrize("kernel", ["path_pool", "wave_queue"])
 def test_equal_distances_and_equal_hits_resolve_as_in_the_reference_on_the_device(kernel):
     """Device side of the hand-derived traversal KAT (tests/test_oracle_kat.py tie_scene): child boxes entered at the same
     distance, triangles hit at the same t; BVHTraversal.cuh:51,63-70 make the triangle of child 1 win.  A camera with a zero

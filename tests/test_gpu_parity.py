@@ -249,7 +249,7 @@ def test_counters_match_oracle(renderer, scene, kw):
         for k in names:
             assert got[k] == want[k], (kernel, k, got[k], want[k])
         if kernel == "path_pool":
-            assert got["sampler_tries"] == want["sphere_iters"]
+            assert got["sampler_tries"] == want["sphere_iters_traced"]       # (the reference's draw after the last bounce is never used: the kernel skips it)
 
 
 @pytest.mark.parametrize("stripe_rows,world", [(8, 2), (8, 8), (16, 3), (5, 4)])
@@ -333,13 +333,6 @@ def test_batch_split_over_several_launches_keeps_sum_order():
     r, ref, ref_acc = _render_with_env({"DRT_SAMPLE_MB": "1"}, "cornell_box", 320, 200, 5, 4)
     compare(r.GetRenderTargetImage(), ref, "split batch")
     compare(r.GetAccumulationBuffer(), ref_acc, "split batch accum")
-
-
-def test_first_kernel_still_matches():
-    """pixel_walk (DRT_KERNEL=pixel_walk), kept for A/B measurements, stays bit-exact too."""
-    r, ref, _ = _render_with_env({"DRT_KERNEL": "pixel_walk"}, "suzanne_plane", 128, 72, 2, 2)
-    assert r.kernelInfo().startswith("pixel_walk")
-    compare(r.GetRenderTargetImage(), ref, "pixel_walk")
 
 
 @pytest.mark.parametrize("votes", [(1, 1, 1, 1), (64, 64, 64, 64), (3, 60, 2, 50)])
