@@ -80,10 +80,10 @@ class RendererSettings(C.Structure):
 
 class MaterialModel(C.Structure):
     """include/drt.h drt_material_model: opt-in emissive term / metallic lobe (NOT reference behaviour; all zero = reference image)."""
-    _fields_ = [("emissive", C.c_int32), ("specular", C.c_int32), ("emissive_scale", C.c_float), ("_reserved", C.c_int32)]
+    _fields_ = [("emissive", C.c_int32), ("specular", C.c_int32), ("emissive_scale", C.c_float), ("transmission", C.c_int32)]
 
-    def __init__(self, emissive=0, specular=0, emissive_scale=1.0):
-        super().__init__(int(emissive), int(specular), float(emissive_scale), 0)
+    def __init__(self, emissive=0, specular=0, emissive_scale=1.0, transmission=0):
+        super().__init__(int(emissive), int(specular), float(emissive_scale), int(transmission))
 
 
 class _CameraPOD(C.Structure):
@@ -321,10 +321,11 @@ class Scene:
         a = (C.c_float * 3)(*albedo)
         return _check(_lib.drt_scene_add_material(self._h, a, albedo_tex))
 
-    def addMaterialEx(self, albedo, albedo_tex=-1, emissive=(0, 0, 0), roughness=0.0, metallic=False):
+    def addMaterialEx(self, albedo, albedo_tex=-1, emissive=(0, 0, 0), roughness=0.0, metallic=False, transmission=False, refractive_index=1.45):
         """A material with the fields only the opt-in material model reads (Renderer.setMaterialModel)."""
         m = np.zeros(1, MATERIAL_DTYPE)
-        m["albedo"], m["emissive"], m["albedo_tex"], m["roughness"], m["metallic"], m["refractive_index"] = albedo, emissive, albedo_tex, roughness, int(bool(metallic)), 1.45
+        m["albedo"], m["emissive"], m["albedo_tex"], m["roughness"], m["metallic"] = albedo, emissive, albedo_tex, roughness, int(bool(metallic))
+        m["transmission"], m["refractive_index"] = int(bool(transmission)), refractive_index
         return _check(_lib.drt_scene_add_material_ex(self._h, m.ctypes.data))
 
     def addTexture(self, texels):
@@ -485,9 +486,9 @@ class Renderer:
     def _push_settings(self):
         _check(_lib.drt_renderer_set_settings(self._h, C.byref(self.m_RendererSettings)))
 
-    def setMaterialModel(self, emissive=0, specular=0, emissive_scale=1.0):
-        """Opt-in extension (drt_material_model): emissive term and / or metallic lobe.  Off (the default) = the reference's image."""
-        m = MaterialModel(emissive, specular, emissive_scale)
+    def setMaterialModel(self, emissive=0, specular=0, emissive_scale=1.0, transmission=0):
+        """Opt-in extension (drt_material_model): emissive term, metallic lobe, dielectric lobe.  Off (the default) = the reference's image."""
+        m = MaterialModel(emissive, specular, emissive_scale, transmission)
         _check(_lib.drt_renderer_set_material_model(self._h, C.byref(m)))
 
     def Render(self, cam, scene):

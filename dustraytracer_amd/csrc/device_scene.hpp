@@ -42,7 +42,7 @@ struct alignas(16) MatDev { float albedo[3]; int32_t tex; };
 struct alignas(16) TexDev { int32_t width, height, comps; uint32_t offset; };
 // Material fields the reference loads and never reads (Material.cuh:9,17,20; Scene.cu:71-75): only the opt-in material model
 // (drt_renderer_set_material_model) reads them, and only the general kernel
-struct alignas(16) MatExt { float emissive[3]; float roughness; int32_t metallic; int32_t _pad[3]; };
+struct alignas(16) MatExt { float emissive[3]; float roughness; int32_t metallic; int32_t transmission; float refractive_index; int32_t _pad; };
 
 // Host-side image of the device buffers.
 struct PackedScene {
@@ -112,6 +112,7 @@ struct FrameParams {
     // opt-in material model (not reference behaviour; all zero = the reference's image): see include/drt.h drt_material_model
     int32_t ext_emissive, ext_specular;
     float ext_emissive_scale;
+    int32_t ext_transmission;
     int32_t inline_resolve;                    // the launch holds ONE frame: the tracing kernel adds each sample to the running sum and
                                                // writes the resolved texel itself (RenderKernel.cu:29-34), no sample buffer, no resolve kernel
 };

@@ -130,7 +130,7 @@ struct drt_renderer {
     DeviceArray<TriCold> d_cold;
     DeviceArray<MatDev> d_mats;
     DeviceArray<MatExt> d_mats_ext;
-    drt_material_model material_model = { 0, 0, 1.0f, 0 };
+    drt_material_model material_model = { 0, 0, 1.0f, 0 };       // emissive, specular, emissive_scale, transmission
     DeviceArray<TexDev> d_texs;
     DeviceArray<uint8_t> d_texels;
     SceneView view;
@@ -412,6 +412,7 @@ void drt_renderer_destroy(drt_renderer *r) {
     if (r->pool_scratch.aux) (void)hipFree(r->pool_scratch.aux);
     if (r->pool_scratch.aux_slot) (void)hipFree(r->pool_scratch.aux_slot);
     if (r->pool_scratch.aux_light) (void)hipFree(r->pool_scratch.aux_light);
+    if (r->pool_scratch.aux_next) (void)hipFree(r->pool_scratch.aux_next);
     if (r->samples) (void)hipFree(r->samples);
     if (r->ev_start) (void)hipEventDestroy(r->ev_start);
     if (r->ev_stop) (void)hipEventDestroy(r->ev_stop);
@@ -638,6 +639,7 @@ static void fill_frame_params(const drt_renderer *r, const drt_camera *cam, Fram
     fp.render_mode = s.render_mode; fp.debug_mode = s.debug_mode;
     fp.ext_emissive = r->material_model.emissive != 0; fp.ext_specular = r->material_model.specular != 0;
     fp.ext_emissive_scale = r->material_model.emissive_scale;
+    fp.ext_transmission = r->material_model.transmission != 0;
     fp.width = r->width; fp.height = r->height;
     fp.stripe_rows = r->stripe_rows; fp.rank = r->rank; fp.world = r->world; fp.local_rows = r->local_rows;
     fp.accum = r->cur_accum(); fp.rgba = r->cur_rgba();
@@ -720,10 +722,12 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
             }
             unsigned int *const queue_head = r->tile_counter + (size_t)(r->counters_used++) * kQueueHeadBlockWords;
             bool pool_hbm_scene = false;
-            if (r->use_path_pool && !material_ext &&
+            if (r->use_path_pool &&
                 path_pool_supports(r->view, fp, r->bvh_depth, wave_queue_scene_lds_bytes(r->view), &pool_hbm_scene) && (r->pool_launched = true))
                 HIP_TRY(launch_path_pool(r->view, fp, r->bvh_depth, r->scene_has_alpha, pool_hbm_scene, r->pool_t_class, r->pool_tuning, r->pool_scratch, queue_head, r->samples, launch_status,
                                          r->num_cus, r->stream, &r->kernel_name, r->launch_shape));
+            else if (fp.ext_transmission)
+                return fail(DRT_ERR_UNSUPPORTED, "the dielectric lobe of drt_material_model is rendered by path_pool only (not: debug views, DRT_KERNEL=wave_queue, trees beyond 32 767 nodes, bounce limits beyond 30 000)");
             else
             HIP_TRY(launch_wave_queue(r->view, fp, r->bvh_depth, r->counting ? 2 : (material_ext ? 1 : 0), r->scene_has_alpha, queue_head,
                                       r->samples, r->num_cus, r->stream, &r->kernel_name, r->launch_shape, r->wq_cache));

@@ -57,13 +57,14 @@ constexpr int kNQ = 9;                               // queues: N, T0..T3, B, E,
 enum : int { QN = 0, QT0 = 1, QB = 5, QE = 6, QR = 7, QS = 8 };
 constexpr uint32_t kEmptyId = 0xFFFFu;                // ring entry: path id | (lap & 15) << 12; ids stop at 4031, so 0xFFFF is never an entry
 constexpr uint32_t kIdMask = 0xFFFu;
-constexpr uint32_t kMaxPoolPaths = 4032u;
+[[maybe_unused]] constexpr uint32_t kMaxPoolPaths = 4032u;
 constexpr uint32_t kSampleShards = (uint32_t)kPoolSampleShards, kSampleShardStride = (uint32_t)kPoolSampleShardStride;     // (render_kernels.hpp)
 constexpr uint32_t kNoPrim = 0xFFFu;                 // word W: hit triangle (12 bits, kNoPrim = none) | bounce index << 12 (16 bits) | kHasSample
 constexpr uint32_t kHasSample = 1u << 28;
 constexpr uint32_t kShadow = 1u << 29;               // the traversal under way is the sun's shadow ray (RayTest, BVHTraversal.cuh:76-134)
 constexpr uint32_t kBackFace = 1u << 30;             // the shaded hit was seen from behind: its normal is -face normal (ClosestHit.cuh:17-24)
 constexpr uint32_t kOccluded = 1u << 31;             // the shadow ray hit something
+constexpr uint32_t kMetal = 1u << 27;                // material-model builds: the direction being drawn is the mirror lobe's (R finds roughness and normal again from the hit triangle)
 constexpr int kMaxPoolThreads = 1024;                // up to 16 waves per workgroup = 4 per SIMD (128 VGPRs each)
 
 typedef uint32_t pp_u32x4 __attribute__((ext_vector_type(4)));
@@ -169,6 +170,7 @@ struct PoolParams {
     uint4 *aux;                // HBM, [workgroup][path]: {throughput, seed} -- what only B and E touch stays out of LDS
     float4 *aux_light;         // HBM, [workgroup][path]: light gathered so far (sunlight builds; lean paths gather light only where they end)
     uint32_t *aux_slot;        // HBM, [workgroup][path]: where the path's sample goes in `samples`
+    float4 *aux_next;          // HBM, [workgroup][path][2]: material-model builds with sunlight: what B decided about the continuation ray, kept across the shadow traversal
     unsigned int *status;      // device word: != 0 after an aborted launch
     unsigned long long *stats; // STATS build: per queue {batches, lanes, ticks} (3 x kNQ), then claim ticks, idle polls, lost claims, wave ticks
 };
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
     auto PA = [&]() -> const PoolParams & { return *(const PoolParams *)&ka->pp; };
 
     constexpr bool STATS = (FLAGS & 1) != 0, SUN = (FLAGS & 2) != 0, ALPHA = (FLAGS & 4) != 0, HBM = (FLAGS & 8) != 0;
+    constexpr bool EXT = (FLAGS & 16) != 0;          // the opt-in material model (drt.h drt_material_model): emissive term, mirror lobe, dielectric lobe
     constexpr uint32_t kWordBytes = HBM ? 16u : 4u, kStackEntryBytes = HBM ? 6u : 8u;
     extern __shared__ uint4 lds_raw[];
     const int tid = threadIdx.x;
@@ -223,6 +226,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
     uint4 *const aux = PA().aux + (size_t)blockIdx.x * P;
     uint32_t *const aux_slot = PA().aux_slot + (size_t)blockIdx.x * P;
     float4 *const aux_light = PA().aux_light + (size_t)blockIdx.x * P;
+    float4 *const aux_next = EXT ? PA().aux_next + (size_t)blockIdx.x * P * 2u : nullptr;
 
     if (FP().span && lane == 0) atomicMax(&FP().span[0], ~(unsigned long long)wall_clock64());
 
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
     };
     // ---- the path's words: meta (flags, bounce index; + hit triangle in the lds-scene build, + stack height in the hbm-scene build) ----
     auto meta_at = [&](uint32_t id) -> uint32_t { return qW + id * kWordBytes; };
-    auto bounce_of = [&](uint32_t meta) -> uint32_t { return HBM ? (meta & 0xFFFFu) : ((meta >> 12) & 0xFFFFu); };
+    auto bounce_of = [&](uint32_t meta) -> uint32_t { return HBM ? (meta & 0xFFFFu) : ((meta >> 12) & (EXT ? 0x7FFFu : 0xFFFFu)); };      // (EXT: bit 27 is kMetal; path_pool_supports caps the bounce limit)
     auto prim_of = [&](uint32_t id, uint32_t meta) -> uint32_t { return HBM ? ld1(meta_at(id) + 4u) : (meta & 0xFFFu); };
     // (prim: only the lds-scene build keeps it in this word; the hbm-scene build's stays where T wrote it)
     auto make_meta = [&](uint32_t prim, uint32_t bounce, uint32_t flags) -> uint32_t { return HBM ? (bounce | flags) : (prim | (bounce << 12) | flags); };
@@ -627,6 +631,12 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
         bool need_dir = false;
         f3 dir_origin = mk3(0, 0, 0), dir_normal = mk3(0, 0, 0), dir_thr = mk3(1, 1, 1);
         uint32_t dir_seed = 0, dir_bounce = 0, dir_tries = 0;
+        // material model (EXT): the mirror lobe draws the same candidates; the ray is reflect(v, N) [in dir_normal] + roughness * candidate,
+        // and the path ends if that points into the surface (below dir_n, the shading normal)
+        bool dir_metal = false, dir_back = false;
+        float dir_rough = 0.0f;
+        f3 dir_n = mk3(0, 0, 0);
+        uint32_t dir_prim = kNoPrim;
         auto draw_and_launch = [&](bool store_throughput) {
             f3 p = mk3(0, 0, 0);
             bool have = false;
@@ -642,12 +652,19 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                     // the RNG state goes on with the path (:91 of the next bounce reads it); B also has a new throughput
                     if (store_throughput) aux[id] = make_uint4(f2u(dir_thr.x), f2u(dir_thr.y), f2u(dir_thr.z), dir_seed);
                     else reinterpret_cast<uint32_t *>(aux + id)[3] = dir_seed;
-                    launch_ray(tr, make_ray(dir_origin, dir_normal + p), dir_bounce, true);                 // :134
+                    const f3 d = (EXT && dir_metal) ? dir_normal + p * dir_rough : dir_normal + p;       // :134 / the mirror lobe
+                    if (EXT && dir_metal && !(dot(d, dir_n) > 0.0f)) {
+                        // scattered into the surface: absorbed -- the path ends here without reaching the sky
+                        st1(qA + id * 16u + 12u, 0u);
+                        st1(meta_at(id), make_meta(kNoPrim, 0u, kHasSample));
+                        dest = QE;
+                    } else launch_ray(tr, make_ray(dir_origin, d), dir_bounce, true);
                 } else {
                     if (store_throughput) aux[id] = make_uint4(f2u(dir_thr.x), f2u(dir_thr.y), f2u(dir_thr.z), dir_seed);
                     st4(qA + id * 16u, make_uint4(f2u(dir_origin.x), f2u(dir_origin.y), f2u(dir_origin.z), dir_seed));
                     st4(qB + id * 16u, make_uint4(f2u(dir_normal.x), f2u(dir_normal.y), f2u(dir_normal.z), dir_tries));
-                    st1(meta_at(id), make_meta(kNoPrim, dir_bounce, kHasSample));
+                    if (EXT && dir_metal) st1(meta_at(id), make_meta(dir_prim, dir_bounce, kHasSample | kMetal | (dir_back ? kBackFace : 0u)));   // (hbm-scene: the hit triangle stays in word 1)
+                    else st1(meta_at(id), make_meta(kNoPrim, dir_bounce, kHasSample));
                     dest = QR;
                 }
             }
@@ -768,7 +785,16 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                 need_dir = true;
                 dir_origin = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); dir_seed = A.w;
                 dir_normal = mk3(u2f(B.x), u2f(B.y), u2f(B.z)); dir_tries = B.w;
-                dir_bounce = bounce_of(ld1(meta_at(id)));
+                const uint32_t W = ld1(meta_at(id));
+                dir_bounce = bounce_of(W);
+                if (EXT && (W & kMetal)) {                     // the mirror lobe: roughness and shading normal again from the hit triangle
+                    dir_prim = held(prim_of(id, W), SC().n_tris, 0x800u);
+                    dir_back = (W & kBackFace) != 0;
+                    const f3 fn = fetch_face_normal((int)dir_prim);
+                    dir_n = dir_back ? (-1.f * fn) : fn;
+                    dir_rough = SC().mats_ext[held((uint32_t)fetch_cold((int)dir_prim).material, SC().n_mats, 0x2000u)].roughness;
+                    dir_metal = true;
+                }
             }
             draw_and_launch(false);
         } else if (q == QB) {
@@ -793,20 +819,67 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                 const TriCold cold = fetch_cold(hit_prim);                                 // :111-118
                 const MatDev mat = fetch_mat(cold.material);
                 count(mat.tex < 0 ? C_HFLAT : C_HTEX);
+                // ---- opt-in material model (EXT builds; drt.h drt_material_model -- this library's rule, stated first in oracle/drt_oracle.c) ----
+                MatExt ext;
+                ext.emissive[0] = ext.emissive[1] = ext.emissive[2] = 0; ext.roughness = 0; ext.metallic = 0; ext.transmission = 0; ext.refractive_index = 1;
+                if (EXT) ext = SC().mats_ext[held((uint32_t)cold.material, SC().n_mats, 0x2000u)];
+                if (EXT && FP().ext_emissive) {              // emission seen through the path so far, before this hit's albedo
+                    float4 *const lp = aux_light + id;
+                    const f3 light = mk3(lp->x, lp->y, lp->z) + (ld3(ext.emissive) * FP().ext_emissive_scale) * throughput;
+                    *lp = make_float4(light.x, light.y, light.z, 0.0f);
+                }
                 if (mat.tex < 0) throughput = throughput * ld3(mat.albedo);
                 else throughput = throughput * tex_get_pixel<true>(SC(), fetch_tex(mat.tex), interp_uv(cold, uvw));
                 const f3 origin = position + (normal * 0.001f);                            // :121
+                const bool glass = EXT && FP().ext_transmission && ext.transmission != 0;
+                const bool mirror = EXT && !glass && FP().ext_specular && ext.metallic != 0;
+                f3 refl = mk3(0, 0, 0);
+                if (EXT && (glass || mirror)) { const f3 v = normalize(ray.dir); refl = v - normal * (2.0f * dot(v, normal)); }
+                // the dielectric interface (Random.cu:26-40): the continuation ray is decided here, with one randomFloat -- after the
+                // sun's draws, which come first in the reference's iteration (:124-134)
+                auto dielectric = [&](uint32_t &rng, f3 &o2, f3 &d2) {
+                    const f3 v = normalize(ray.dir);
+                    const float cos_theta = fminf(dot(mk3(v.x * -1.f, v.y * -1.f, v.z * -1.f), normal), 1.0f);      // Random.cu:28
+                    const float ri = front_face ? 1.0f / ext.refractive_index : ext.refractive_index;
+                    const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+                    bool reflect = ri * sin_theta > 1.0f;                                                        // total internal reflection
+                    float r0 = (1 - ri) / (1 + ri);                                                              // :37-39, pow(x, 5) = ((x x)(x x)) x
+                    r0 = r0 * r0;
+                    const float om = 1 - cos_theta;
+                    const float schlick = r0 + (1 - r0) * (((om * om) * (om * om)) * om);
+                    if (!reflect) reflect = schlick > random_float(rng);
+                    if (reflect) { o2 = origin; d2 = refl; }
+                    else {
+                        const f3 perp = (v + normal * cos_theta) * ri;                                           // :29
+                        const f3 par = normal * (-sqrtf(fabsf(1.0f - dot(perp, perp))));                         // :30
+                        o2 = position - (normal * 0.001f); d2 = perp + par;
+                    }
+                };
                 if (SUN) {
                     // :124-128: the sun's shadow ray starts where the bounce ray will (its origin waits in A), the normal is found
                     // again from the triangle and the side bit; the rest of this iteration is S's, after the shadow traversal
                     const Ray sun_ray = make_ray(origin, ld3(FP().sunpos) + random_unit_vec3(seed) * 1.5f);
+                    if (EXT) {
+                        // what S will need and the shadow ray overwrites: tag 2 = the dielectric's ray, decided now; 1 = mirror lobe
+                        // {reflect(v, N), roughness}; 0 = the reference's diffuse bounce
+                        f3 o2 = origin, d2 = refl;
+                        if (glass) dielectric(seed, o2, d2);
+                        aux_next[2u * id] = make_float4(d2.x, d2.y, d2.z, glass ? 2.0f : (mirror ? 1.0f : 0.0f));
+                        aux_next[2u * id + 1u] = glass ? make_float4(o2.x, o2.y, o2.z, 0.0f) : make_float4(ext.roughness, 0.0f, 0.0f, 0.0f);
+                    }
                     aux[id] = make_uint4(f2u(throughput.x), f2u(throughput.y), f2u(throughput.z), seed);
                     launch_shadow(tr, sun_ray, make_meta((uint32_t)hit_prim, bounce, kHasSample | kShadow | (front_face ? 0u : kBackFace)));
                 } else {
                     ++bounce;
-                    if ((int)bounce <= FP().bounce_limit) {                                  // :88 loop condition
-                        need_dir = true; dir_origin = origin; dir_normal = normal; dir_seed = seed; dir_bounce = bounce; dir_tries = 0;
+                    if ((int)bounce <= FP().bounce_limit && glass) {
+                        f3 o2, d2;
+                        dielectric(seed, o2, d2);
+                        aux[id] = make_uint4(f2u(throughput.x), f2u(throughput.y), f2u(throughput.z), seed);
+                        launch_ray(tr, make_ray(o2, d2), bounce, true);
+                    } else if ((int)bounce <= FP().bounce_limit) {                           // :88 loop condition
+                        need_dir = true; dir_origin = origin; dir_normal = mirror ? refl : normal; dir_seed = seed; dir_bounce = bounce; dir_tries = 0;
                         dir_thr = throughput;
+                        if (EXT) { dir_metal = mirror; dir_rough = ext.roughness; dir_n = normal; dir_prim = (uint32_t)hit_prim; dir_back = !front_face; }
                     } else {
                         st1(qA + id * 16u + 12u, 0u);    // the path ends without reaching the sky: E adds no light (hit_t != FLT_MAX)
                         dest = QE;
@@ -826,10 +899,19 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                     *lp = make_float4(light.x, light.y, light.z, 0.0f);
                 }
                 const uint32_t bounce = bounce_of(W) + 1u;
-                if ((int)bounce <= FP().bounce_limit) {                                      // :88 loop condition
-                    const f3 fn = fetch_face_normal((int)checked(prim_of(id, W), SC().n_tris, 0x1000u));
-                    need_dir = true; dir_origin = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); dir_normal = (W & kBackFace) ? (-1.f * fn) : fn;
+                float4 next0 = make_float4(0, 0, 0, 0);
+                if (EXT) next0 = aux_next[2u * id];                                         // what B decided (tag in .w)
+                if ((int)bounce <= FP().bounce_limit && EXT && next0.w == 2.0f) {
+                    const float4 o2 = aux_next[2u * id + 1u];                               // the dielectric's ray: nothing left to draw
+                    launch_ray(tr, make_ray(mk3(o2.x, o2.y, o2.z), mk3(next0.x, next0.y, next0.z)), bounce, true);
+                } else if ((int)bounce <= FP().bounce_limit) {                               // :88 loop condition
+                    dir_prim = checked(prim_of(id, W), SC().n_tris, 0x1000u);
+                    const f3 fn = fetch_face_normal((int)dir_prim);
+                    dir_back = (W & kBackFace) != 0;
+                    const f3 n = dir_back ? (-1.f * fn) : fn;
+                    need_dir = true; dir_origin = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); dir_normal = n;
                     dir_seed = E.w; dir_bounce = bounce; dir_tries = 0;
+                    if (EXT && next0.w == 1.0f) { dir_metal = true; dir_normal = mk3(next0.x, next0.y, next0.z); dir_rough = aux_next[2u * id + 1u].x; dir_n = n; }
                 } else {
                     st1(qA + id * 16u + 12u, 0u);        // the path ends without reaching the sky
                     st1(meta_at(id), make_meta(kNoPrim, 0u, kHasSample));
@@ -846,7 +928,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                     const uint4 B = ld4(qB + id * 16u);
                     const float hit_t = u2f(ld1(qA + id * 16u + 12u));
                     f3 light = mk3(0, 0, 0);
-                    if (SUN) { const float4 l = aux_light[id]; light = mk3(l.x, l.y, l.z); }
+                    if (SUN || (EXT && FP().ext_emissive)) { const float4 l = aux_light[id]; light = mk3(l.x, l.y, l.z); }
                     if (!(hit_t < FLT_MAX))                                                // miss: :99-108
                         light = light + sky_model(mk3(u2f(B.x), u2f(B.y), u2f(B.z)), ld3(FP().sky_color)) * mk3(u2f(E.x), u2f(E.y), u2f(E.z)) * FP().sky_intensity;
                     if (FP().tone_mapping) light = uncharted2_filmic(light, FP().exposure);    // :165-169 (wave-uniform branches)
@@ -909,7 +991,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                         launch_ray(tr, ray, 0u, FP().bounce_limit >= 0);
                         aux[id] = make_uint4(f2u(1.0f), f2u(1.0f), f2u(1.0f), seed);
                         aux_slot[id] = slot;
-                        if (SUN) aux_light[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (SUN || (EXT && FP().ext_emissive)) aux_light[id] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     } else {
                         st1(meta_at(id), HBM ? 0u : kNoPrim);       // a sample id outside the image (partial tile): the slot asks again
                         dest = QE;
@@ -968,6 +1050,24 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
 
 }  // namespace
 
+#ifdef DRT_POOL_EXT_TU
+// ---- this translation unit (kernel_path_pool_ext.o): the material-model variants of the kernel, nothing else ----
+const void *path_pool_ext_kernel(int flags) {        // (untyped: the argument struct lives in each translation unit's anonymous namespace)
+    switch (flags & 14) {
+    case 0: return reinterpret_cast<const void *>(path_pool_kernel<16>);
+    case 2: return reinterpret_cast<const void *>(path_pool_kernel<18>);
+    case 4: return reinterpret_cast<const void *>(path_pool_kernel<20>);
+    case 6: return reinterpret_cast<const void *>(path_pool_kernel<22>);
+    case 8: return reinterpret_cast<const void *>(path_pool_kernel<24>);
+    case 10: return reinterpret_cast<const void *>(path_pool_kernel<26>);
+    case 12: return reinterpret_cast<const void *>(path_pool_kernel<28>);
+    default: return reinterpret_cast<const void *>(path_pool_kernel<30>);
+    }
+}
+}  // namespace drt
+#else
+const void *path_pool_ext_kernel(int flags);                    // kernel_path_pool_ext.o
+
 // Leaf step counts (two triangles per step) -> upper bounds of the first three T queues, chosen so that the steps a
 // batch wastes on shorter leaves (every lane runs as long as the batch's longest leaf) are fewest, each leaf weighted by
 // its size.  At most a dozen distinct values: exhaustive.
@@ -1001,6 +1101,7 @@ void path_pool_leaf_classes(const std::vector<LeafRange> &leaves, uint32_t out[3
 bool path_pool_supports(const SceneView &sc, const FrameParams &fp, int bvh_depth, size_t scene_lds_bytes, bool *hbm_scene) {
     if (fp.render_mode != 0) return false;                                                // no debug views (wave_queue's general build)
     if (fp.bounce_limit > 60000 || bvh_depth > 200) return false;                         // bounce index in 16 bits, stack height in 8
+    if ((fp.ext_emissive || fp.ext_specular || fp.ext_transmission) && fp.bounce_limit > 30000) return false;      // (material-model builds: 15 bits)
     if (sc.root_ref == kNoNode) return false;
     static const size_t scene_limit = std::getenv("DRT_POOL_SCENE_KB") ? (size_t)std::atoi(std::getenv("DRT_POOL_SCENE_KB")) * 1024 : kLdsSceneBytes;
     static const bool hbm_allowed = !(std::getenv("DRT_POOL_HBM") && std::atoi(std::getenv("DRT_POOL_HBM")) == 0);
@@ -1080,12 +1181,17 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
                                             path_pool_kernel<4>, path_pool_kernel<5>, path_pool_kernel<6>, path_pool_kernel<7>,
                                             path_pool_kernel<8>, path_pool_kernel<9>, path_pool_kernel<10>, path_pool_kernel<11>,
                                             path_pool_kernel<12>, path_pool_kernel<13>, path_pool_kernel<14>, path_pool_kernel<15> };
-    static const char *const names[8] = { "path_pool<lean,lds-scene>", "path_pool<lean+sun,lds-scene>", "path_pool<lean+alpha,lds-scene>",
-                                          "path_pool<lean+alpha+sun,lds-scene>", "path_pool<lean,hbm-scene>", "path_pool<lean+sun,hbm-scene>",
-                                          "path_pool<lean+alpha,hbm-scene>", "path_pool<lean+alpha+sun,hbm-scene>" };
-    const PoolKernel kernel = kernels[flags];
+    static const char *const names[16] = { "path_pool<lean,lds-scene>", "path_pool<lean+sun,lds-scene>", "path_pool<lean+alpha,lds-scene>",
+                                           "path_pool<lean+alpha+sun,lds-scene>", "path_pool<lean,hbm-scene>", "path_pool<lean+sun,hbm-scene>",
+                                           "path_pool<lean+alpha,hbm-scene>", "path_pool<lean+alpha+sun,hbm-scene>",
+                                           "path_pool<materials,lds-scene>", "path_pool<materials+sun,lds-scene>", "path_pool<materials+alpha,lds-scene>",
+                                           "path_pool<materials+alpha+sun,lds-scene>", "path_pool<materials,hbm-scene>", "path_pool<materials+sun,hbm-scene>",
+                                           "path_pool<materials+alpha,hbm-scene>", "path_pool<materials+alpha+sun,hbm-scene>" };
+    const bool material_model = fp.ext_emissive || fp.ext_specular || fp.ext_transmission;
+    // (the material-model variants live in a translation unit of their own, kernel_path_pool_ext.o: no statistics builds of them)
+    const void *const kernel = material_model ? path_pool_ext_kernel(flags & ~1) : reinterpret_cast<const void *>(kernels[flags]);
     if (lay.total > 64u * 1024u) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total);
+        hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total);
         if (e != hipSuccess) return e;
     }
     int per_cu = 0;
@@ -1129,19 +1235,29 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
         if (ea != hipSuccess) return ea;
         scratch.slots = slots;
     }
+    if (material_model && fp.enable_sunlight && slots > scratch.next_slots) {            // (only the material model with sunlight uses it)
+        if (scratch.aux_next) (void)hipFree(scratch.aux_next);
+        scratch.aux_next = nullptr; scratch.next_slots = 0;
+        const hipError_t ea = hipMalloc(&scratch.aux_next, slots * 32);
+        if (ea != hipSuccess) return ea;
+        scratch.next_slots = slots;
+    }
     pp.aux = static_cast<uint4 *>(scratch.aux); pp.aux_slot = static_cast<uint32_t *>(scratch.aux_slot);
     pp.aux_light = static_cast<float4 *>(scratch.aux_light);
+    pp.aux_next = static_cast<float4 *>(scratch.aux_next);
     hipError_t e = hipSuccess;                 // (sample_counter: kPoolSampleShards zeroed counters, kPoolSampleShardStride words apart -- drt_capi.cpp hands out zeroed blocks)
-    if (kernel_name) *kernel_name = names[flags >> 1];
+    if (kernel_name) *kernel_name = names[(flags >> 1) + (material_model ? 8 : 0)];
     if (launch_shape) { launch_shape[0] = (int)stack_entries; launch_shape[1] = per_cu; launch_shape[2] = (int)(lay.total / 1024); launch_shape[3] = threads; launch_shape[4] = (int)P; }
     FrameParams fq = fp;
     fq.inline_resolve = fp.n_frames == 1 ? 1 : 0;
     PoolArgs args;
     args.sc = sc; args.fp = fq; args.pp = pp; args.sample_counter = sample_counter; args.samples = static_cast<float4 *>(samples);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)want), dim3(threads), lay.total, stream, args);
-    e = hipGetLastError();
+    void *kernel_args[] = { &args };
+    e = hipLaunchKernel(kernel, dim3((unsigned)want), dim3(threads), kernel_args, lay.total, stream);
+    if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess || fq.inline_resolve) return e;
     return launch_resolve(fp, samples, stream);
 }
 
 }  // namespace drt
+#endif  // DRT_POOL_EXT_TU

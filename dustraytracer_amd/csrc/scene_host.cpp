@@ -812,6 +812,8 @@ PackedScene HostScene::pack() const {
         std::memcpy(e.emissive, m.emissive, 12);
         e.roughness = m.roughness;
         e.metallic = m.metallic ? 1 : 0;
+        e.transmission = m.transmission ? 1 : 0;
+        e.refractive_index = m.refractive_index;
         ps.mats_ext.push_back(e);
     }
     for (const HostTexture &t : textures) {

@@ -260,9 +260,9 @@ public:
     uint32_t getSampleCount() const { return drt_renderer_sample_count(handle); }
     void resetAccumulationBuffer() { drt::check(group ? drt_group_reset(group) : drt_renderer_reset(handle)); }
     int deviceCount() const { return group ? (int)drt_group_size(group) : 1; }
-    // opt-in material model (drt.h drt_material_model; off = the reference's image): emissive term, metallic lobe
-    void setMaterialModel(bool emissive, bool specular, float emissive_scale = 1.0f) {
-        drt_material_model m = { emissive ? 1 : 0, specular ? 1 : 0, emissive_scale, 0 };
+    // opt-in material model (drt.h drt_material_model; off = the reference's image): emissive term, metallic lobe, dielectric lobe
+    void setMaterialModel(bool emissive, bool specular, float emissive_scale = 1.0f, bool transmission = false) {
+        drt_material_model m = { emissive ? 1 : 0, specular ? 1 : 0, emissive_scale, transmission ? 1 : 0 };
         const int n = deviceCount();
         for (int i = 0; i < n; i++) drt::check(drt_renderer_set_material_model(group ? drt_group_renderer(group, i) : handle, &m));
     }

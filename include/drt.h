@@ -61,12 +61,20 @@ typedef struct drt_settings {
  * zero (the default) the image is the reference's, bit for bit.  emissive != 0: a hit adds  EmmisiveFactor * emissive_scale *
  * throughput  (the throughput before that hit's albedo).  specular != 0: a hit on a Metallic material continues along
  * reflect(normalize(ray.dir), N) + Roughness * randomUnitSphereVec3(seed)  -- the same random draws as the diffuse bounce -- and the
- * path ends if that direction points into the surface.  Rendered by the general wave_queue kernel. */
+ * path ends if that direction points into the surface.  transmission != 0: a hit on a Transmission material (Material.cuh:20-21; the
+ * reference's loader never sets it: drt_scene_add_material_ex does) is a dielectric interface, computed with the reference's own
+ * unused helpers refract / reflectance (CudaMath/Random.cu:26-40):  v = normalize(ray.dir), cos = fminf(dot(-v, N), 1), ri = front face ?
+ * 1 / refractive_index : refractive_index;  total internal reflection (ri * sqrtf(1 - cos^2) > 1) or reflectance(cos, ri) >
+ * randomFloat(seed)  ->  continue along reflect(v, N) from P + 0.001 N, else along refract(v, N, ri) from P - 0.001 N.  That one
+ * randomFloat replaces the bounce's randomUnitSphereVec3; pow(x, 5) is ((x x)(x x)) x; takes precedence over the metallic lobe.
+ * The rule is this library's (the reference has none): oracle/drt_oracle.c states it first, tests/test_material_model.py checks
+ * cases that can be derived by hand -- "parity unpinned" by construction.
+ * Rendered by path_pool (every lobe) and by the general wave_queue kernel (emissive, specular). */
 typedef struct drt_material_model {
     int32_t emissive;
     int32_t specular;
     float   emissive_scale;        /* default 1 */
-    int32_t _reserved;
+    int32_t transmission;
 } drt_material_model;
 
 /* Core/Scene/Camera.cuh:30-47: the fields the kernel reads (Camera.cu:82-123). */

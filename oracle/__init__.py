@@ -18,7 +18,7 @@ NODE_DTYPE = np.dtype([("is_leaf", "<i4"), ("bmin", "<f4", 3), ("bmax", "<f4", 3
 TRI_DTYPE = np.dtype([("centroid", "<f4", 3), ("p", "<f4", (3, 3)), ("n", "<f4", (3, 3)),
                       ("uv", "<f4", (3, 2)), ("face_n", "<f4", 3), ("material", "<i4")])
 MAT_DTYPE = np.dtype([("albedo", "<f4", 3), ("albedo_tex", "<i4")])
-MAT_EXT_DTYPE = np.dtype([("emissive", "<f4", 3), ("roughness", "<f4"), ("metallic", "<i4")])
+MAT_EXT_DTYPE = np.dtype([("emissive", "<f4", 3), ("roughness", "<f4"), ("metallic", "<i4"), ("transmission", "<i4"), ("refractive_index", "<f4")])
 assert NODE_DTYPE.itemsize == 44 and TRI_DTYPE.itemsize == 124 and MAT_DTYPE.itemsize == 16
 
 
@@ -42,7 +42,7 @@ class Camera(C.Structure):
 class SceneC(C.Structure):
     _fields_ = [("tris", C.c_void_p), ("n_tris", C.c_int32), ("nodes", C.c_void_p), ("n_nodes", C.c_int32),
                 ("mats", C.c_void_p), ("n_mats", C.c_int32), ("texs", C.c_void_p), ("n_texs", C.c_int32),
-                ("mats_ext", C.c_void_p), ("ext_emissive", C.c_int32), ("ext_specular", C.c_int32), ("ext_emissive_scale", C.c_float)]
+                ("mats_ext", C.c_void_p), ("ext_emissive", C.c_int32), ("ext_specular", C.c_int32), ("ext_emissive_scale", C.c_float), ("ext_transmission", C.c_int32)]
 
 
 class Counters(C.Structure):
@@ -129,9 +129,12 @@ class Scene:
 
     def __init__(self, tris, materials, textures, materials_ext=None):
         self.mats_ext = np.zeros(max(len(materials), 1), MAT_EXT_DTYPE)          # (emissive3, roughness, metallic) per material
-        for i, e in enumerate(materials_ext or []):
-            self.mats_ext[i]["emissive"], self.mats_ext[i]["roughness"], self.mats_ext[i]["metallic"] = e
-        self.material_model = (0, 0, 1.0)                                        # opt-in extension: (emissive, specular, emissive_scale)
+        self.mats_ext["refractive_index"] = 1.45                                   # Material.cuh:21
+        for i, e in enumerate(materials_ext or []):                                # (emissive3, roughness, metallic[, transmission, refractive_index])
+            self.mats_ext[i]["emissive"], self.mats_ext[i]["roughness"], self.mats_ext[i]["metallic"] = e[:3]
+            if len(e) > 3:
+                self.mats_ext[i]["transmission"], self.mats_ext[i]["refractive_index"] = e[3], e[4]
+        self.material_model = (0, 0, 1.0)                                        # opt-in extension: (emissive, specular, emissive_scale[, transmission])
         self.tris = np.ascontiguousarray(tris, dtype=TRI_DTYPE)
         self.nodes = np.zeros(0, NODE_DTYPE)
         self.mats = np.zeros(max(len(materials), 1), MAT_DTYPE)
@@ -182,6 +185,7 @@ class Scene:
         s.texs, s.n_texs = C.addressof(self._tex_c), len(self.textures)
         s.mats_ext = self.mats_ext.ctypes.data
         s.ext_emissive, s.ext_specular, s.ext_emissive_scale = int(self.material_model[0]), int(self.material_model[1]), float(self.material_model[2])
+        s.ext_transmission = int(self.material_model[3]) if len(self.material_model) > 3 else 0
         return s
 
 

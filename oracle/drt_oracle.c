@@ -237,6 +237,7 @@ typedef struct {
     float t;
     f3 normal, position, color, uvw;
     const o_triangle *prim;
+    int front_face;                    /* HitPayload.cuh:10 (the reference stores it and never reads it; the opt-in dielectric lobe does) */
 } hit_payload;
 
 #define STACK_SIZE 64     /* BVH/BVHTraversal.cuh:17 */
@@ -373,7 +374,7 @@ static hit_payload trace_ray(const ray_t *ray, const o_scene *sc, o_counters *cn
     out.prim = w.prim;                                   /* ClosestHit */
     out.uvw = w.uvw;
     out.t = w.t;
-    closest_hit_frame(ray, w.t, ld3(w.prim->face_n), &out.position, &out.normal);
+    out.front_face = closest_hit_frame(ray, w.t, ld3(w.prim->face_n), &out.position, &out.normal);
     return out;
 }
 
@@ -525,6 +526,29 @@ static f3 ray_gen(uint32_t x, uint32_t y, uint32_t max_x, uint32_t max_y, const 
         }
 
         const uint64_t iters_before = cnt ? cnt->sphere_iters : 0;
+        if (ext && sc->ext_transmission && ext->transmission && !debug) {
+            /* opt-in: dielectric interface (the reference's refract / reflectance, CudaMath/Random.cu:26-40, which nothing calls) */
+            f3 v = normalize3(ray.dir);
+            float cos_theta = fminf(dot3(scale3(v, -1.f), payload.normal), 1.0f);                /* Random.cu:28 */
+            float ri = payload.front_face ? 1.0f / ext->refractive_index : ext->refractive_index;
+            float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+            int reflect = ri * sin_theta > 1.0f;
+            float r0 = (1 - ri) / (1 + ri);                                                       /* Random.cu:37-39 */
+            r0 = r0 * r0;
+            float one_minus = 1 - cos_theta;
+            float p5 = ((one_minus * one_minus) * (one_minus * one_minus)) * one_minus;          /* pow(1 - cosine, 5) */
+            float refl = r0 + (1 - r0) * p5;
+            if (!reflect) reflect = refl > random_float(&seed);
+            if (reflect) {
+                f3 dir = sub3(v, scale3(payload.normal, 2.0f * dot3(v, payload.normal)));
+                ray = make_ray(new_origin, dir);
+            } else {
+                f3 perp = scale3(add3(v, scale3(payload.normal, cos_theta)), ri);                 /* Random.cu:29 */
+                f3 par = scale3(payload.normal, -sqrtf(fabsf(1.0f - dot3(perp, perp))));          /* :30 */
+                ray = make_ray(sub3(payload.position, scale3(payload.normal, 0.001f)), add3(perp, par));
+            }
+            continue;
+        }
         f3 fuzz = random_unit_sphere_vec3(&seed, cnt ? &cnt->sphere_iters : NULL);
         if (cnt && i < bounces) cnt->sphere_iters_traced += cnt->sphere_iters - iters_before;
         if (ext && sc->ext_specular && ext->metallic && !debug) {   /* opt-in: mirror lobe, fuzzed by the roughness */

@@ -92,12 +92,20 @@ typedef struct {
     float   emissive[3];    /* EmmisiveFactor */
     float   roughness;      /* Roughness */
     int32_t metallic;       /* Metallic (metallicFactor > 0) */
+    int32_t transmission;   /* Transmission (Material.cuh:20; the reference's loader never sets it) */
+    float   refractive_index; /* refractive_index (Material.cuh:21, default 1.45) */
 } o_material_ext;
 
 /* Opt-in extension (NOT reference behaviour; everything 0 / NULL = the reference's image, bit for bit):
  *   emissive  a hit adds  EmmisiveFactor * emissive_scale * throughput  (the throughput before this hit's albedo)
  *   specular  a hit on a Metallic material continues along  reflect(normalize(ray.dir), N) + Roughness * randomUnitSphereVec3
- *             (the same draws as the diffuse bounce; the path ends if that points into the surface) instead of N + ... */
+ *             (the same draws as the diffuse bounce; the path ends if that points into the surface) instead of N + ...
+ *   transmission  a hit on a Transmission material is a dielectric interface, with the reference's own unused helpers
+ *             (Random.cu:26-40): v = normalize(ray.dir), cos = fminf(dot(-v, N), 1), ri = front face ? 1 / refractive_index :
+ *             refractive_index; if ri * sqrtf(1 - cos * cos) > 1 (total internal reflection) or reflectance(cos, ri) > randomFloat(seed)
+ *             the path continues along reflect(v, N) from P + 0.001 N, else along refract(v, N, ri) from P - 0.001 N (through the
+ *             surface).  One randomFloat replaces the bounce's randomUnitSphereVec3; pow(x, 5) is ((x x)(x x)) x.  Takes
+ *             precedence over the metallic lobe. */
 typedef struct {
     const o_triangle *tris;   int32_t n_tris;
     const o_bvh_node *nodes;  int32_t n_nodes;   /* root = n_nodes-1 (Kernel/TraceRay.cu:20) */
@@ -106,6 +114,7 @@ typedef struct {
     const o_material_ext *mats_ext;              /* n_mats entries, or NULL */
     int32_t ext_emissive, ext_specular;
     float   ext_emissive_scale;
+    int32_t ext_transmission;
 } o_scene;
 
 /* Exact work counters; summed over everything rendered. */
