@@ -98,6 +98,8 @@ DRT_DEV bool lds_cas_seen(uint32_t off, uint32_t expect, uint32_t desired, uint3
     seen = expect;
     return ok;
 }
+DRT_DEV void lds_add64(uint32_t off, unsigned long long v) { (void)__hip_atomic_fetch_add((PP_LDS(unsigned long long) *)off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+DRT_DEV unsigned long long ld64(uint32_t off) { return *(PP_LDS(const unsigned long long) *)off; }
 DRT_DEV void lds_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 DRT_DEV void lds_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 #else       // host pass: never called, only parsed
@@ -117,6 +119,8 @@ __device__ inline void st_id(uint32_t, uint32_t) {}
 __device__ inline uint32_t lds_add(uint32_t, uint32_t) { return 0; }
 __device__ inline bool lds_cas(uint32_t, uint32_t, uint32_t) { return false; }
 __device__ inline bool lds_cas_seen(uint32_t, uint32_t, uint32_t, uint32_t &) { return false; }
+__device__ inline void lds_add64(uint32_t, unsigned long long) {}
+__device__ inline unsigned long long ld64(uint32_t) { return 0; }
 __device__ inline void lds_release() {}
 __device__ inline void lds_acquire() {}
 #endif
@@ -134,10 +138,11 @@ struct PoolLayout {
 __host__ __device__ inline PoolLayout pool_layout(uint32_t P, uint32_t ring_cap, uint32_t stack_entries, uint32_t scene_bytes, uint32_t cold_bytes,
                                                   uint32_t n_rings = (uint32_t)kNQ - 1u /* S's ring exists in sunlight builds only */,
                                                   uint32_t word_bytes = 4u /* 16 in the hbm-scene build: {meta, hit triangle, leaf end, -} */,
-                                                  uint32_t stack_entry_bytes = 8u /* 6 in the hbm-scene build */) {
+                                                  uint32_t stack_entry_bytes = 8u /* 6 in the hbm-scene build */,
+                                                  uint32_t stats_bytes = 0u /* statistics build: per-queue {batches, lanes, ticks} sums of the workgroup */) {
     PoolLayout l;
     l.ctrl = 0;                                     // head/tail pairs of the kNQ queues (8 B each), then {live, abort}, {exhausted, -}
-    l.rings = 128;
+    l.rings = 128 + stats_bytes;                    // (the statistics block sits between the control words and the rings)
     l.quads = l.rings + n_rings * ring_cap * 2u;
     l.words = l.quads + 2u * P * 16u;
     l.stack = l.words + P * word_bytes;
@@ -146,7 +151,7 @@ __host__ __device__ inline PoolLayout pool_layout(uint32_t P, uint32_t ring_cap,
     l.total = l.cold + cold_bytes;
     return l;
 }
-constexpr uint32_t kCtrlLive = 80, kCtrlAbort = 84, kCtrlExhausted = 88;      // (the pairs of lanes 10 and 11 of the control read)
+constexpr uint32_t kCtrlLive = 80, kCtrlAbort = 84, kCtrlExhausted = 88, kCtrlStats = 128, kStatsBytes = 256;      // (the pairs of lanes 10 and 11 of the control read)
 __host__ __device__ inline uint32_t pool_scene_bytes(const SceneView &sc) { return sc.n_inner * 64u + sc.n_tris * 48u; }   // (leaf ranges ride in the references)
 __host__ __device__ inline uint32_t pool_cold_bytes(const SceneView &sc) { return sc.n_tris * 32u + sc.n_mats * 16u + sc.n_texs * 16u; }
 
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
     const uint32_t ring_mask = k_ring_cap - 1u;
     const bool cold_lds = PA().cold_in_lds != 0;
     constexpr uint32_t kRings = SUN ? (uint32_t)kNQ : (uint32_t)kNQ - 1u;
-    const PoolLayout lay = pool_layout(P, k_ring_cap, k_stack_entries, HBM ? 0u : pool_scene_bytes(SC()), cold_lds ? pool_cold_bytes(SC()) : 0u, kRings, kWordBytes, kStackEntryBytes);
+    const PoolLayout lay = pool_layout(P, k_ring_cap, k_stack_entries, HBM ? 0u : pool_scene_bytes(SC()), cold_lds ? pool_cold_bytes(SC()) : 0u, kRings, kWordBytes, kStackEntryBytes, STATS ? kStatsBytes : 0u);
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds_raw);      // low 32 bits of the flat address = LDS offset
     const uint32_t ctrl = lds_base + lay.ctrl, rings = lds_base + lay.rings, stack = lds_base + lay.stack;
     const uint32_t qA = lds_base + lay.quads, qB = qA + P * 16u, qW = lds_base + lay.words;
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
             for (uint32_t i = tid; i < SC().n_texs; i += wg) st4(lds_texs + i * 16u, g_texs[i]);
         }
         for (uint32_t i = tid; i < kRings * k_ring_cap; i += wg) st_id(rings + i * 2u, kEmptyId);
-        for (uint32_t i = tid; i < 32u; i += wg) st1(ctrl + i * 4u, 0u);
+        for (uint32_t i = tid; i < 32u + (STATS ? kStatsBytes / 4u : 0u); i += wg) st1(ctrl + i * 4u, 0u);
         for (uint32_t i = tid; i < P; i += wg) {                                                  // no sample yet
             if (HBM) st4(qW + i * 16u, make_uint4(0u, 0u, 0u, 0u));                                // {meta, hit triangle, leaf end, -}: all of it
             else st1(qW + i * 4u, kNoPrim);
@@ -521,8 +526,9 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
     uint32_t my_shard = (uint32_t)__builtin_amdgcn_readfirstlane((int)blockIdx.x) & (kSampleShards - 1u);      // scalar: the sample counter this wave draws from
     uint32_t rot = (uint32_t)__builtin_amdgcn_readfirstlane(wave) % (uint32_t)kNQ;      // scalar: where this wave's round robin over the queues stands
     unsigned long long s_work[6] = { 0, 0, 0, 0, 0, 0 };      // STATS: N iterations / lane pops, T steps / lane steps, direction-try iterations / lane tries
-    unsigned long long s_batches[kNQ], s_lanes[kNQ], s_ticks[kNQ], s_claim = 0, s_idle = 0, s_lost = 0, s_fail = 0, s_fail_ticks = 0, s_idle_ticks = 0;
-    for (int k = 0; k < kNQ; k++) s_batches[k] = s_lanes[k] = s_ticks[k] = 0;
+    // (the per-queue sums {batches, lanes, ticks} are kept in LDS, kCtrlStats: indexed by the queue, they would otherwise be arrays in scratch
+    // memory and the statistics build a different kernel from the one it describes)
+    unsigned long long s_claim = 0, s_idle = 0, s_lost = 0, s_fail = 0, s_fail_ticks = 0, s_idle_ticks = 0;
     const unsigned long long s_t_start = STATS ? __builtin_amdgcn_s_memtime() : 0;
     unsigned long long s_t0 = s_t_start;
     for (;;) {
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
         }
         lds_acquire();
         unsigned long long s_t1 = 0;
-        if (STATS) { s_t1 = __builtin_amdgcn_s_memtime(); s_claim += s_t1 - s_t0; s_batches[q]++; s_lanes[q] += n; }
+        if (STATS) { s_t1 = __builtin_amdgcn_s_memtime(); s_claim += s_t1 - s_t0; if (lane == 0) { lds_add64(ctrl + kCtrlStats + (uint32_t)q * 24u, 1ull); lds_add64(ctrl + kCtrlStats + (uint32_t)q * 24u + 8u, (unsigned long long)n); } }
         if (!HBM) __builtin_amdgcn_s_setprio(0);
         int dest = -1;                                                    // queue this lane's path goes to next
         Trav tr = trav_idle();                                            // this lane's traversal registers (an N batch loads them, a launch sets them)
@@ -1031,7 +1037,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
         lds_release();
         push_group(dest, id);
         if ((HBM || STATS) && pp_ballot(violations != 0) != 0) { if (violations != 0 && PA().status) atomicOr(PA().status, violations); violations = 0; }
-        if (STATS) s_ticks[q] += __builtin_amdgcn_s_memtime() - s_t1;
+        if (STATS && lane == 0) lds_add64(ctrl + kCtrlStats + (uint32_t)q * 24u + 16u, __builtin_amdgcn_s_memtime() - s_t1);
     }
 
     if (FP().span && lane == 0) atomicMax(&FP().span[1], (unsigned long long)wall_clock64());
@@ -1039,8 +1045,11 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
         // (wave sums by DPP-free butterfly through ds_bpermute would save atomics; a counting launch is not timed)
         for (int k = 0; k < C_COUNT; k++) if (work[k]) atomicAdd(&FP().counters[k == C_TRIES ? 23 : k], (unsigned long long)work[k]);     // (drt_counters: the ten work counters, 13 words of wave_queue's phase statistics, sampler_tries)
     }
+    if (STATS && PA().stats) {                               // (every wave gets here: the loop ends for all of them, by `live == 0` or by the abort flag)
+        __syncthreads();
+        if (tid < 3 * kNQ) atomicAdd(&PA().stats[tid], ld64(ctrl + kCtrlStats + (uint32_t)tid * 8u));
+    }
     if (STATS && PA().stats && lane == 0) {
-        for (int k = 0; k < kNQ; k++) { atomicAdd(&PA().stats[3 * k], s_batches[k]); atomicAdd(&PA().stats[3 * k + 1], s_lanes[k]); atomicAdd(&PA().stats[3 * k + 2], s_ticks[k]); }
         atomicAdd(&PA().stats[3 * kNQ], s_claim); atomicAdd(&PA().stats[3 * kNQ + 1], s_idle); atomicAdd(&PA().stats[3 * kNQ + 2], s_lost);
         atomicAdd(&PA().stats[3 * kNQ + 3], __builtin_amdgcn_s_memtime() - s_t_start);
         for (int k = 0; k < 6; k++) atomicAdd(&PA().stats[3 * kNQ + 7 + k], s_work[k]);
@@ -1144,10 +1153,11 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     // Workgroups per CU, pool size and threads: the most paths the CU's 160 KB of LDS hold (rings are sized to the next power of
     // two, so 1024 paths per workgroup is a sweet spot), then as many threads as paths, at most 24 waves per CU (16 in one workgroup).
     const uint32_t n_rings = fp.enable_sunlight ? (uint32_t)kNQ : (uint32_t)kNQ - 1u;
+    const uint32_t stats_bytes = (tune.stats || fp.counters) ? kStatsBytes : 0u;         // (the statistics build keeps its per-queue sums in LDS)
     auto lds_for = [&](uint32_t paths, uint32_t &cap) {
         cap = 64;
         while (cap < paths) cap *= 2;
-        return pool_layout(paths, cap, stack_entries, scene_bytes, cold_bytes, n_rings, word_bytes, stack_entry_bytes).total;
+        return pool_layout(paths, cap, stack_entries, scene_bytes, cold_bytes, n_rings, word_bytes, stack_entry_bytes, stats_bytes).total;
     };
     uint32_t P = 0, ring_cap = 64;
     int groups = 1;
@@ -1168,7 +1178,7 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
         if (P == 0) return hipErrorInvalidValue;
         (void)lds_for(P, ring_cap);
     }
-    const PoolLayout lay = pool_layout(P, ring_cap, stack_entries, scene_bytes, cold_bytes, n_rings, word_bytes, stack_entry_bytes);
+    const PoolLayout lay = pool_layout(P, ring_cap, stack_entries, scene_bytes, cold_bytes, n_rings, word_bytes, stack_entry_bytes, stats_bytes);
     if (lay.total > 160u * 1024u) return hipErrorInvalidValue;
     const int flags = ((tune.stats || fp.counters) ? 1 : 0) | (fp.enable_sunlight ? 2 : 0) | (scene_has_alpha ? 4 : 0) | (hbm_scene ? 8 : 0);
     int threads;
