@@ -1150,7 +1150,7 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     const uint32_t word_bytes = hbm_scene ? 16u : 4u, stack_entry_bytes = hbm_scene ? 6u : 8u;
     // the shading records go to LDS too when they are small (cornell: 1.2 KB): B's load chain triangle -> material ->
     // texture header then runs through LDS instead of three dependent HBM / L2 round trips
-    const uint32_t cold_bytes = pool_cold_bytes(sc) <= (tune.cold_lds_kb >= 0 ? (uint32_t)tune.cold_lds_kb * 1024u : 4096u) ? pool_cold_bytes(sc) : 0u;
+    uint32_t cold_bytes = pool_cold_bytes(sc) <= (tune.cold_lds_kb >= 0 ? (uint32_t)tune.cold_lds_kb * 1024u : 4096u) ? pool_cold_bytes(sc) : 0u;
     // Workgroups per CU, pool size and threads: the most paths the CU's 160 KB of LDS hold (rings are sized to the next power of
     // two, so 1024 paths per workgroup is a sweet spot), then as many threads as paths, at most 24 waves per CU (16 in one workgroup).
     const uint32_t n_rings = fp.enable_sunlight ? (uint32_t)kNQ : (uint32_t)kNQ - 1u;
@@ -1167,15 +1167,21 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
         while (P > 64u && lds_for(P, ring_cap) > 160u * 1024u) P -= 64u;
         (void)lds_for(P, ring_cap);
     } else {
-        uint32_t best_total = 0;
         // (hbm-scene: one pool per CU -- what counts there is resident waves AND spare paths, and one big pool has both)
-        for (int g = 1; g <= (hbm_scene ? 1 : 3); g++)
-            for (uint32_t paths = kMaxPoolPaths; paths >= 256u; paths -= 64u) {
-                uint32_t cap;
-                if (lds_for(paths, cap) * (uint32_t)g > 160u * 1024u) continue;
-                if (paths * (uint32_t)g >= best_total) { best_total = paths * (uint32_t)g; P = paths; groups = g; }
-                break;
-            }
+        auto best_pool = [&]() {
+            uint32_t best_total = 0;
+            for (int g = 1; g <= (hbm_scene ? 1 : 3); g++)
+                for (uint32_t paths = kMaxPoolPaths; paths >= 256u; paths -= 64u) {
+                    uint32_t cap;
+                    if (lds_for(paths, cap) * (uint32_t)g > 160u * 1024u) continue;
+                    if (paths * (uint32_t)g >= best_total) { best_total = paths * (uint32_t)g; P = paths; groups = g; }
+                    break;
+                }
+        };
+        best_pool();
+        // path_pool_supports sizes its smallest pool without the staged shading records: a small scene under a very deep tree may
+        // leave no room for them -- the records then stay in global memory rather than the launch failing
+        if (P == 0 && cold_bytes > 0) { cold_bytes = 0; best_pool(); }
         if (P == 0) return hipErrorInvalidValue;
         (void)lds_for(P, ring_cap);
     }
