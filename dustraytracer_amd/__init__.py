@@ -295,7 +295,7 @@ class Scene:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and _lib is not None:              # (at interpreter shutdown the module's globals may be gone already)
             _lib.drt_scene_destroy(h)
 
     def loadGLTFmodel(self, filepath, strict=False):
@@ -419,7 +419,7 @@ class RendererGroup:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and _lib is not None:              # (at interpreter shutdown the module's globals may be gone already)
             _lib.drt_group_destroy(h)
 
     def size(self):
@@ -477,7 +477,7 @@ class Renderer:
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
-        if h:
+        if h and _lib is not None:              # (at interpreter shutdown the module's globals may be gone already)
             _lib.drt_renderer_destroy(h)
 
     def ResizeBuffer(self, width, height):
