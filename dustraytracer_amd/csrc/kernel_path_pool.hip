@@ -638,10 +638,10 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
         f3 dir_origin = mk3(0, 0, 0), dir_normal = mk3(0, 0, 0), dir_thr = mk3(1, 1, 1);
         uint32_t dir_seed = 0, dir_bounce = 0, dir_tries = 0;
         // material model (EXT): the mirror lobe draws the same candidates; the ray is reflect(v, N) [in dir_normal] + roughness * candidate,
-        // and the path ends if that points into the surface (below dir_n, the shading normal)
+        // and the path ends if that points into the surface (below the shading normal: +- the face normal of dir_prim, found again when needed --
+        // carrying it through the candidate loop cost the three registers that kept <16> at one workgroup per CU)
         bool dir_metal = false, dir_back = false;
         float dir_rough = 0.0f;
-        f3 dir_n = mk3(0, 0, 0);
         uint32_t dir_prim = kNoPrim;
         auto draw_and_launch = [&](bool store_throughput) {
             f3 p = mk3(0, 0, 0);
@@ -659,7 +659,12 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                     if (store_throughput) aux[id] = make_uint4(f2u(dir_thr.x), f2u(dir_thr.y), f2u(dir_thr.z), dir_seed);
                     else reinterpret_cast<uint32_t *>(aux + id)[3] = dir_seed;
                     const f3 d = (EXT && dir_metal) ? dir_normal + p * dir_rough : dir_normal + p;       // :134 / the mirror lobe
-                    if (EXT && dir_metal && !(dot(d, dir_n) > 0.0f)) {
+                    bool absorbed = false;
+                    if (EXT && dir_metal) {
+                        const f3 fn = fetch_face_normal((int)dir_prim);
+                        absorbed = !(dot(d, dir_back ? (-1.f * fn) : fn) > 0.0f);
+                    }
+                    if (absorbed) {
                         // scattered into the surface: absorbed -- the path ends here without reaching the sky
                         st1(qA + id * 16u + 12u, 0u);
                         st1(meta_at(id), make_meta(kNoPrim, 0u, kHasSample));
@@ -797,8 +802,6 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                 if (EXT && (W & kMetal)) {                     // the mirror lobe: roughness and shading normal again from the hit triangle
                     dir_prim = held(prim_of(id, W), SC().n_tris, 0x800u);
                     dir_back = (W & kBackFace) != 0;
-                    const f3 fn = fetch_face_normal((int)dir_prim);
-                    dir_n = dir_back ? (-1.f * fn) : fn;
                     dir_rough = SC().mats_ext[held((uint32_t)fetch_cold((int)dir_prim).material, SC().n_mats, 0x2000u)].roughness;
                     dir_metal = true;
                 }
@@ -886,7 +889,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                     } else if ((int)bounce <= FP().bounce_limit) {                           // :88 loop condition
                         need_dir = true; dir_origin = origin; dir_normal = mirror ? refl : normal; dir_seed = seed; dir_bounce = bounce; dir_tries = 0;
                         dir_thr = throughput;
-                        if (EXT) { dir_metal = mirror; dir_rough = ext.roughness; dir_n = normal; dir_prim = (uint32_t)hit_prim; dir_back = !front_face; }
+                        if (EXT) { dir_metal = mirror; dir_rough = ext.roughness; dir_prim = (uint32_t)hit_prim; dir_back = !front_face; }
                     } else {
                         st1(qA + id * 16u + 12u, 0u);    // the path ends without reaching the sky: E adds no light (hit_t != FLT_MAX)
                         dest = QE;
@@ -918,7 +921,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                     const f3 n = dir_back ? (-1.f * fn) : fn;
                     need_dir = true; dir_origin = mk3(u2f(A.x), u2f(A.y), u2f(A.z)); dir_normal = n;
                     dir_seed = E.w; dir_bounce = bounce; dir_tries = 0;
-                    if (EXT && next0.w == 1.0f) { dir_metal = true; dir_normal = mk3(next0.x, next0.y, next0.z); dir_rough = aux_next[2u * id + 1u].x; dir_n = n; }
+                    if (EXT && next0.w == 1.0f) { dir_metal = true; dir_normal = mk3(next0.x, next0.y, next0.z); dir_rough = aux_next[2u * id + 1u].x; }
                 } else {
                     st1(qA + id * 16u + 12u, 0u);        // the path ends without reaching the sky
                     st1(meta_at(id), make_meta(kNoPrim, 0u, kHasSample));
