@@ -259,3 +259,20 @@ def test_editor_gl_shim_shows_a_rendered_frame(tmp_path):
         r.Render(cam, sc)
     want8 = np.rint(np.clip(r.GetRenderTargetImage(), 0, 1) * np.float32(255)).astype(np.uint8)[::-1]
     assert np.array_equal(png, want8)
+
+
+def test_isa_slot_table_behind_algorithmic_frac_is_reproducible(tmp_path):
+    """profiles/r03_isa_slots.json -- the VALU issue slots of one call of each reference operation, which bench.py multiplies with
+    the exact work counters to get roofline.algorithmic_frac -- is what tools/isa_by_phase.py --slots-json makes of
+    tools/probes/isa_probes.hip with the Makefile's flags TODAY (no GPU needed: hipcc cross-compiles, llvm-objdump and
+    llvm-symbolizer count).  A change of device_math.hpp that changes an operation's cost must come with a regenerated table."""
+    import json, os, shutil, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc here")
+    out = tmp_path / "slots.json"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "isa_by_phase.py"), "--slots-json", str(out)], check=True, capture_output=True, timeout=600)
+    fresh = json.load(open(out))["per_call"]
+    committed = json.load(open(os.path.join(root, "profiles", "r03_isa_slots.json")))["per_call"]
+    assert fresh == committed
+    assert 55 <= committed["tri_test"]["slots"] <= 70 and 20 <= committed["box_test"]["slots"] <= 30        # Moeller-Trumbore / slab test, unfused fp32
