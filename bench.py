@@ -9,7 +9,7 @@ A "step" is one full progressive render of the frame: reset the accumulation buf
 of the workload (W x H x spp paths: ray generation, BVH traversal, shading, accumulate, resolve) and,
 for N > 1, gather the rank-local framebuffer stripes on rank 0 over RCCL and assemble the image.
 Inputs (scene, BVH, textures) are resident in HBM before the timed region.  One JSON line on rank 0.
-Steps are independent frames; --frames-in-flight (default 3; 2 for the one-second steps of room 4K) of them are enqueued at a time, each on its own
+Steps are independent frames; --frames-in-flight (default 4; 2 for the one-second steps of room 4K) of them are enqueued at a time, each on its own
 renderer + HIP stream, so the end-of-launch drain of one frame and its gather overlap the next frame's
 ramp-up.  Every step still does all of its work inside the timed region (drained before the closing sync).
 
@@ -59,7 +59,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the cpu_baseline leg (0 = skip)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="independent frames (steps) kept in flight, each on its own renderer + HIP stream: the drain of one "
-                         "frame overlaps the ramp-up of the next (1 = strictly one after the other).  Default 3; 4 for shards of a frame; 2 for the "
+                         "frame overlaps the ramp-up of the next (1 = strictly one after the other).  Default 4; 2 for the "
                          "workload whose step is a second long (room 4K / 64 spp: 800 ms with 2 in flight, 896 with 3)")
     ap.add_argument("--emulate-shard", default="", help="R/W: render only rank R's stripes of a W-way split on ONE GPU, no gather "
                     "(what one GPU of a W-GPU run computes; for tuning small-shard behaviour on a 1-GPU box)")
@@ -211,10 +211,10 @@ def main_group(args):
 def main():
     args = parse_args()
     if args.frames_in_flight <= 0:
-        # whole frames: 3 (2 for the one-second steps of room 4K); shards of a frame (several GPUs, or --emulate-shard): 4 -- their
-        # launches are a few refills of the pools long, most of it ramp-up and drain, and one more in flight hides more of that
-        sharded = args.gpus > 1 or bool(args.emulate_shard) or int(os.environ.get("WORLD_SIZE", "1")) > 1
-        args.frames_in_flight = 2 if args.workload == "room_4k_64spp_d16" else (4 if sharded else 3)
+        # 4 (on the 8 hardware queues asked for above); 2 for the one-second steps of room 4K.  Launches of a millisecond or less are
+        # mostly ramp-up and drain, and each one more in flight hides more of that: 256^2 x 1 spp 0.083 -> 0.065 ms, the 1/8 shard
+        # 0.40 -> 0.37, suzanne 1.46 -> 1.40; cornell 1080p x 8 spp is the same with 3 and 4 (2.59 ms), 6 is worse everywhere.
+        args.frames_in_flight = 2 if args.workload == "room_4k_64spp_d16" else 4
     if args.group:
         return main_group(args)
     rank = int(os.environ.get("RANK", "0"))
