@@ -389,8 +389,7 @@ drt_renderer *drt_renderer_create(int32_t device) {
         hipMemset(r->records, 0, sizeof(unsigned long long) * 4 * drt_renderer::kRecords) != hipSuccess ||
         hipHostMalloc((void **)&r->records_host, sizeof(unsigned long long) * 4 * drt_renderer::kMaxSpans, hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void **)&r->tile_counter, sizeof(unsigned int) * drt_renderer::kCounters * kQueueHeadBlockWords) != hipSuccess ||
-        hipMemset(r->tile_counter, 0, sizeof(unsigned int) * drt_renderer::kCounters * kQueueHeadBlockWords) != hipSuccess ||
-        false) {
+        hipMemset(r->tile_counter, 0, sizeof(unsigned int) * drt_renderer::kCounters * kQueueHeadBlockWords) != hipSuccess) {
         fail(DRT_ERR_DEVICE, "cannot create HIP events / counter buffer");
         drt_renderer_destroy(r);
         return nullptr;
@@ -722,8 +721,9 @@ static int render_batch_impl(drt_renderer *r, const drt_camera *cam, const drt_s
             }
             unsigned int *const queue_head = r->tile_counter + (size_t)(r->counters_used++) * kQueueHeadBlockWords;
             bool pool_hbm_scene = false;
-            if (r->use_path_pool &&
-                path_pool_supports(r->view, fp, r->bvh_depth, wave_queue_scene_lds_bytes(r->view), &pool_hbm_scene) && (r->pool_launched = true))
+            const bool use_pool = r->use_path_pool && path_pool_supports(r->view, fp, r->bvh_depth, wave_queue_scene_lds_bytes(r->view), &pool_hbm_scene);
+            if (use_pool) r->pool_launched = true;
+            if (use_pool)
                 HIP_TRY(launch_path_pool(r->view, fp, r->bvh_depth, r->scene_has_alpha, pool_hbm_scene, r->pool_t_class, r->pool_tuning, r->pool_scratch, queue_head, r->samples, launch_status,
                                          r->num_cus, r->stream, &r->kernel_name, r->launch_shape));
             else if (fp.ext_transmission)
