@@ -10,11 +10,17 @@ from tests.scenes import SCENES, scene_path
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
-names = sorted(SCENES)
+names = sorted(SCENES) + (["glass_lds", "glass_hbm"] * 2 if os.environ.get("DRT_FUZZ_MATERIALS") == "1" else [])
 loaded = {}
 
 
 def get(name):
+    if name not in loaded and name.startswith("glass"):
+        # the programmatic room with glass, mirror and emissive materials of tests/test_material_model.py (scene in LDS / read from global memory)
+        from tests.test_material_model import _glass_scene
+        sc, osc = _glass_scene(0 if name == "glass_lds" else 3000)
+        p = osc.tris["p"].reshape(-1, 3)
+        loaded[name] = (sc, osc, p.min(0), p.max(0))
     if name not in loaded:
         sc = drt.Scene(); sc.loadGLTFmodel(scene_path(name))
         b = drt.BVHBuilder(); b.m_TargetLeafPrimitivesCount, b.m_BinCount = 20, 8; b.buildIterative(sc)
@@ -35,7 +41,7 @@ for case in range(n_cases):
     elif kind == 1: pos = (lo + hi) / 2 + rng.normal(size=3) * ext                          # around
     elif kind == 2: pos = (lo + hi) / 2 + rng.normal(size=3) * ext * 50                     # far away
     elif kind == 3: pos = lo + np.round(rng.uniform(0, 1, 3) * 4) / 4 * ext                 # on a lattice: often exactly on geometry / box planes
-    elif kind == 4: pos = np.array(SCENES[name][1], np.float64)                             # the benchmark pose
+    elif kind == 4: pos = np.array(SCENES[name][1] if name in SCENES else (0.3, 1.6, 2.8), np.float64)                          # the benchmark pose
     else:           pos = hi + ext * 0.01
     fwd = rng.normal(size=3)
     if rng.integers(4) == 0: fwd = np.eye(3)[rng.integers(3)] * rng.choice([-1, 1])         # axis-aligned: zero components -> inf inverse
@@ -54,6 +60,12 @@ for case in range(n_cases):
     if rng.integers(5) == 0: st.update(sky_intensity=float(rng.uniform(0, 40)), sunlight_intensity=float(rng.uniform(0, 60)),
                                        sunlight_dir=(float(rng.uniform(-1, 1)), float(rng.uniform(0, 1))))
     W, H, frames = int(rng.integers(1, 97)), int(rng.integers(1, 65)), int(rng.integers(1, 4))
+    # DRT_FUZZ_MATERIALS=1: the opt-in material model too (emissive term, mirror lobe, dielectric lobe), any combination, in a third of the cases
+    model = (0, 0, 1.0, 0)
+    if os.environ.get("DRT_FUZZ_MATERIALS") == "1" and (name.startswith("glass") or rng.integers(3) == 0):
+        model = (int(rng.integers(2)), int(rng.integers(2)), float(rng.uniform(0.1, 3.0)), int(rng.integers(2)))
+    if "RenderMode" in st: model = (model[0], model[1], model[2], 0)                          # (debug views go to wave_queue, which has no dielectric lobe)
+    if st.get("ray_bounce_limit", 0) > 12: pass
     cam = drt.Camera(pos); cam.m_Forward_dir = fwd
     ocam = oracle.default_camera(position=tuple(float(v) for v in pos), forward=tuple(float(v) for v in fwd))
     for k, v in cam_kw.items():
@@ -61,16 +73,19 @@ for case in range(n_cases):
     oname = {"enableSunlight": "enable_sunlight", "RenderMode": "render_mode", "DebugMode": "debug_mode"}
     r.m_RendererSettings = drt.RendererSettings(max_samples=frames + 1, **st)
     r.ResizeBuffer(W, H); r.resetAccumulationBuffer()
+    r.setMaterialModel(*model)
+    osc.material_model = model
     r.RenderBatch(cam, sc, frames)
     img = r.GetRenderTargetImage()
     ref, _, _ = oracle.render(osc, ocam, oracle.default_settings(**{oname.get(k, k): v for k, v in st.items()}), W, H, 1, frames, threads=8)
+    osc.material_model = (0, 0, 1.0, 0)
     kernels[r.kernelInfo().split()[0]] = kernels.get(r.kernelInfo().split()[0], 0) + 1
     a, b = img.view(np.uint32), ref.view(np.uint32)
     both_nan = np.isnan(img) & np.isnan(ref)
     nbad = int(((a != b) & ~both_nan).any(axis=-1).sum())
     if nbad:
         bad += 1
-        print("MISMATCH case %d: %s pos %s fwd %s cam %s settings %s %dx%d x%d: %d pixels" % (case, name, pos.tolist(), fwd.tolist(), cam_kw, st, W, H, frames, nbad), flush=True)
+        print("MISMATCH case %d: %s pos %s fwd %s cam %s settings %s model %s %dx%d x%d: %d pixels" % (case, name, pos.tolist(), fwd.tolist(), cam_kw, st, model, W, H, frames, nbad), flush=True)
     if case % 50 == 49:
         print("... %d cases, %d mismatching, %.0f s" % (case + 1, bad, time.time() - t0), flush=True)
 print("cases %d, mismatching %d; kernels used: %s" % (n_cases, bad, kernels))
