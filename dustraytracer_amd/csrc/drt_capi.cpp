@@ -368,6 +368,7 @@ drt_renderer *drt_renderer_create(int32_t device) {
     r->leaf_chain = env_int("DRT_LEAF_CHAIN", r->leaf_chain);
     r->sample_budget = (size_t)std::max(1, env_int("DRT_SAMPLE_MB", 1024)) << 20;
     r->pool_tuning.threads = env_int("DRT_POOL_THREADS", 0); r->pool_tuning.paths = env_int("DRT_POOL_PATHS", 0);
+    r->pool_tuning.stack_lds = env_int("DRT_POOL_STACK_LDS", r->pool_tuning.stack_lds);
     r->pool_tuning.min_fill = env_int("DRT_POOL_MIN_FILL", r->pool_tuning.min_fill);
     r->pool_tuning.patience = env_int("DRT_POOL_PATIENCE", r->pool_tuning.patience);
     r->pool_tuning.n_loop = env_int("DRT_POOL_N_LOOP", r->pool_tuning.n_loop);
@@ -412,6 +413,7 @@ void drt_renderer_destroy(drt_renderer *r) {
     if (r->pool_scratch.aux_slot) (void)hipFree(r->pool_scratch.aux_slot);
     if (r->pool_scratch.aux_light) (void)hipFree(r->pool_scratch.aux_light);
     if (r->pool_scratch.aux_next) (void)hipFree(r->pool_scratch.aux_next);
+    if (r->pool_scratch.aux_stack) (void)hipFree(r->pool_scratch.aux_stack);
     if (r->samples) (void)hipFree(r->samples);
     if (r->ev_start) (void)hipEventDestroy(r->ev_start);
     if (r->ev_stop) (void)hipEventDestroy(r->ev_stop);
@@ -558,8 +560,15 @@ int32_t drt_renderer_launch_count(const drt_renderer *r) { return r ? r->launche
 int drt_renderer_kernel_info(const drt_renderer *r, char *buf, size_t cap) {
     if (!r || !buf || cap == 0) return fail(DRT_ERR_INVALID, "bad argument");
     if (r->launch_shape[1] > 0 && std::strncmp(r->kernel_name, "path_pool", 9) == 0)
-        std::snprintf(buf, cap, "%s stack=%d wg/CU=%d threads=%d paths=%d lds=%dKiB", r->kernel_name, r->launch_shape[0], r->launch_shape[1],
+    {
+        // (launch_shape[0]: stack levels | levels kept in LDS << 8)
+        const int levels = r->launch_shape[0] & 255, in_lds = r->launch_shape[0] >> 8;
+        char stack[48];
+        if (in_lds < levels) std::snprintf(stack, sizeof stack, "%d(%d in LDS)", levels, in_lds);
+        else std::snprintf(stack, sizeof stack, "%d", levels);
+        std::snprintf(buf, cap, "%s stack=%s wg/CU=%d threads=%d paths=%d lds=%dKiB", r->kernel_name, stack, r->launch_shape[1],
                       r->launch_shape[3], r->launch_shape[4], r->launch_shape[2]);
+    }
     else if (r->launch_shape[1] > 0 && std::strncmp(r->kernel_name, "wave_queue", 10) == 0)
         std::snprintf(buf, cap, "%s stack=%d%s wg/CU=%d%s lds=%dKiB", r->kernel_name, r->launch_shape[0], (r->launch_shape[3] & 1) ? "x6B" : ((r->launch_shape[3] & 2) ? " tris=3" : ""),
                       r->launch_shape[1], r->launch_shape[3] >= 512 ? "x512" : "", r->launch_shape[2]);

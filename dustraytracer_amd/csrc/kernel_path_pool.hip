@@ -161,6 +161,7 @@ struct PoolParams {
     uint32_t ring_cap;         // entries per ring: power of two >= P
     uint32_t ring_shift;       // log2(ring_cap): ring position >> ring_shift = the lap, whose low 4 bits tag the entry
     uint32_t stack_entries;    // BVH levels - 1
+    uint32_t stack_lds;        // of which this many (the stack's bottom levels) are kept in LDS; the levels above them in HBM (aux_stack)
     uint32_t total_samples;    // n_chunks * 64 (sample ids beyond the image edge are skipped)
     uint32_t n_chunks, tiles_x;
     uint32_t t_class[3];       // leaf step counts (two triangles per step) up to t_class[i] wait in queue T<i>; larger ones in T3
@@ -175,6 +176,7 @@ struct PoolParams {
     uint4 *aux;                // HBM, [workgroup][path]: {throughput, seed} -- what only B and E touch stays out of LDS
     float4 *aux_light;         // HBM, [workgroup][path]: light gathered so far (sunlight builds; lean paths gather light only where they end)
     uint32_t *aux_slot;        // HBM, [workgroup][path]: where the path's sample goes in `samples`
+    uint2 *aux_stack;          // HBM, [workgroup][level - stack_lds][path]: the stack entries above the levels kept in LDS (deep trees)
     float4 *aux_next;          // HBM, [workgroup][path][2]: material-model builds with sunlight: what B decided about the continuation ray, kept across the shadow traversal
     unsigned int *status;      // device word: != 0 after an aborted launch
     unsigned long long *stats; // STATS build: per queue {batches, lanes, ticks} (3 x kNQ), then claim ticks, idle polls, lost claims, wave ticks
@@ -200,6 +202,7 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
     auto PA = [&]() -> const PoolParams & { return *(const PoolParams *)&ka->pp; };
 
     constexpr bool STATS = (FLAGS & 1) != 0, SUN = (FLAGS & 2) != 0, ALPHA = (FLAGS & 4) != 0, HBM = (FLAGS & 8) != 0;
+    constexpr bool DEEP = (FLAGS & 32) != 0;         // deep tree: only the bottom levels of the traversal stacks are in LDS, the rest in HBM (PoolParams::stack_lds)
     constexpr bool EXT = (FLAGS & 16) != 0;          // the opt-in material model (drt.h drt_material_model): emissive term, mirror lobe, dielectric lobe
     constexpr uint32_t kWordBytes = HBM ? 16u : 4u, kStackEntryBytes = HBM ? 6u : 8u;
     extern __shared__ uint4 lds_raw[];
@@ -218,11 +221,12 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
     const uint32_t k_n_fuse_min = PA().n_fuse_min;
     const uint32_t k_dir_tries = PA().dir_tries;
     const uint32_t k_stack_entries = PA().stack_entries;
+    const uint32_t k_stack_lds = DEEP ? PA().stack_lds : k_stack_entries;
     const uint32_t k_t_class0 = PA().t_class[0], k_t_class1 = PA().t_class[1], k_t_class2 = PA().t_class[2];
     const uint32_t ring_mask = k_ring_cap - 1u;
     const bool cold_lds = PA().cold_in_lds != 0;
     constexpr uint32_t kRings = SUN ? (uint32_t)kNQ : (uint32_t)kNQ - 1u;
-    const PoolLayout lay = pool_layout(P, k_ring_cap, k_stack_entries, HBM ? 0u : pool_scene_bytes(SC()), cold_lds ? pool_cold_bytes(SC()) : 0u, kRings, kWordBytes, kStackEntryBytes, STATS ? kStatsBytes : 0u);
+    const PoolLayout lay = pool_layout(P, k_ring_cap, k_stack_lds, HBM ? 0u : pool_scene_bytes(SC()), cold_lds ? pool_cold_bytes(SC()) : 0u, kRings, kWordBytes, kStackEntryBytes, STATS ? kStatsBytes : 0u);
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds_raw);      // low 32 bits of the flat address = LDS offset
     const uint32_t ctrl = lds_base + lay.ctrl, rings = lds_base + lay.rings, stack = lds_base + lay.stack;
     const uint32_t qA = lds_base + lay.quads, qB = qA + P * 16u, qW = lds_base + lay.words;
@@ -396,15 +400,25 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
     // Stack entries {node reference, slab distance}, [level][path]: 8 bytes in the lds-scene build; the hbm-scene build, whose deep trees
     // make the stacks most of a path's LDS, keeps the distances in one array and 16-bit references (bit 15 = leaf) in another:
     // 6 bytes, a quarter more paths per CU (path_pool_supports: fewer than 32768 interior nodes and leaves)
-    const uint32_t stack_refs = stack + k_stack_entries * P * 4u;
+    // Deep trees: only the bottom k_stack_lds levels of every stack are in LDS; a path that goes deeper keeps the entries above
+    // them in global memory (8 bytes each, [level][path] per workgroup) -- rare accesses, and the LDS they free holds more paths.
+    const uint32_t stack_refs = stack + k_stack_lds * P * 4u;
+    uint2 *const aux_stack = DEEP ? PA().aux_stack + (size_t)blockIdx.x * (k_stack_entries - k_stack_lds) * P : nullptr;
     auto stack_load = [&](int level, uint32_t id) -> uint2 {
-        const uint32_t at = (STATS ? checked((uint32_t)level, k_stack_entries, 0x10000u) : (uint32_t)level) * P + id;   // (LDS: cannot fault)
+        if (DEEP && __builtin_expect((uint32_t)level >= k_stack_lds, 0))
+            return aux_stack[(size_t)(min((uint32_t)level, k_stack_entries - 1u) - k_stack_lds) * P + id];      // (clamped: a level beyond the tree's depth is a logic error, not a fault)
+        const uint32_t at = (uint32_t)level * P + id;   // (LDS: cannot fault)
         if (!HBM) return ld2(stack + at * 8u);
         const uint32_t r16 = ld_u16(stack_refs + at * 2u);
         return make_uint2((r16 & 0x8000u) ? (kLeafBit | (r16 & 0x7FFFu)) : r16, ld1(stack + at * 4u));
     };
     auto stack_store = [&](int level, uint32_t id, uint2 e) {
-        const uint32_t at = (STATS ? checked((uint32_t)level, k_stack_entries, 0x20000u) : (uint32_t)level) * P + id;
+        if (HBM || STATS) violations |= (uint32_t)level >= k_stack_entries ? 0x20000u : 0u;
+        if (DEEP && __builtin_expect((uint32_t)level >= k_stack_lds, 0)) {
+            aux_stack[(size_t)(min((uint32_t)level, k_stack_entries - 1u) - k_stack_lds) * P + id] = e;
+            return;
+        }
+        const uint32_t at = (uint32_t)level * P + id;
         if (!HBM) { st2(stack + at * 8u, e); return; }
         st_u16(stack_refs + at * 2u, (e.x & kLeafBit) ? (0x8000u | (e.x & 0x7FFFu)) : e.x);
         st1(stack + at * 4u, e.y);
@@ -1066,6 +1080,16 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
 #ifdef DRT_POOL_EXT_TU
 // ---- this translation unit (kernel_path_pool_ext.o): the material-model variants of the kernel, nothing else ----
 const void *path_pool_ext_kernel(int flags) {        // (untyped: the argument struct lives in each translation unit's anonymous namespace)
+    if (flags & 32) switch (flags & 14) {
+    case 0: return reinterpret_cast<const void *>(path_pool_kernel<48>);
+    case 2: return reinterpret_cast<const void *>(path_pool_kernel<50>);
+    case 4: return reinterpret_cast<const void *>(path_pool_kernel<52>);
+    case 6: return reinterpret_cast<const void *>(path_pool_kernel<54>);
+    case 8: return reinterpret_cast<const void *>(path_pool_kernel<56>);
+    case 10: return reinterpret_cast<const void *>(path_pool_kernel<58>);
+    case 12: return reinterpret_cast<const void *>(path_pool_kernel<60>);
+    default: return reinterpret_cast<const void *>(path_pool_kernel<62>);
+    }
     switch (flags & 14) {
     case 0: return reinterpret_cast<const void *>(path_pool_kernel<16>);
     case 2: return reinterpret_cast<const void *>(path_pool_kernel<18>);
@@ -1149,6 +1173,14 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     // mod P by multiplication -- were tried too: room's pool grows from 1216 to 1344 paths, and the extra arithmetic in every claim
     // and push costs the 3 % that buys.)
     const uint32_t stack_entries = (uint32_t)std::max(bvh_depth - 1, 1);
+    // The levels of the stacks kept in LDS (tune.stack_lds; 0 = chosen below): all of them, unless the tree is so deep that its
+    // stacks leave one workgroup of 1024 threads fewer than ~1.3 paths per lane -- the pool then runs short of full batches.
+    // In that case only the stacks' bottom levels stay in LDS and the rest goes to HBM (path_pool_kernel<FLAGS | 32>): the
+    // entries a path pushes when it is deep in the tree are few, and the paths the freed LDS holds are worth more.  Measured
+    // (tools/experiments/r03/sweep_stack_lds.sh; levels in LDS -> paths -> Msamples/s): dense_monkey, 14 levels: all 1024 -> 9 513,
+    // 8 -> 1 344 -> 10 593, 6 -> 1 536 -> 10 503; cs16_dust, 15 levels: all -> 1 024 -> 1 094, 7 -> 1 408 -> 1 235; room 4K, 7 levels: all ->
+    // 1 216 -> 847, 5 -> 1 472 -> 864, 3 -> 1 856 -> 862: beyond ~1 350 paths per 1 024 threads more paths buy nothing.
+    uint32_t stack_lds = tune.stack_lds > 0 ? std::min<uint32_t>((uint32_t)tune.stack_lds, stack_entries) : stack_entries;
     const uint32_t scene_bytes = hbm_scene ? 0u : pool_scene_bytes(sc);
     const uint32_t word_bytes = hbm_scene ? 16u : 4u, stack_entry_bytes = hbm_scene ? 6u : 8u;
     // the shading records go to LDS too when they are small (cornell: 1.2 KB): B's load chain triangle -> material ->
@@ -1161,7 +1193,7 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     auto lds_for = [&](uint32_t paths, uint32_t &cap) {
         cap = 64;
         while (cap < paths) cap *= 2;
-        return pool_layout(paths, cap, stack_entries, scene_bytes, cold_bytes, n_rings, word_bytes, stack_entry_bytes, stats_bytes).total;
+        return pool_layout(paths, cap, stack_lds, scene_bytes, cold_bytes, n_rings, word_bytes, stack_entry_bytes, stats_bytes).total;
     };
     uint32_t P = 0, ring_cap = 64;
     int groups = 1;
@@ -1186,9 +1218,16 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
         // leave no room for them -- the records then stay in global memory rather than the launch failing
         if (P == 0 && cold_bytes > 0) { cold_bytes = 0; best_pool(); }
         if (P == 0) return hipErrorInvalidValue;
+        if (tune.stack_lds == 0 && groups == 1 && P < 1280u && stack_entries > 2u) {
+            // deep tree: the most levels in LDS that still leave room for 1344 paths (or, failing that, two levels)
+            for (stack_lds = stack_entries - 1u; ; --stack_lds) {
+                best_pool();
+                if (P * (uint32_t)groups >= 1344u || stack_lds == 2u) break;
+            }
+        }
         (void)lds_for(P, ring_cap);
     }
-    const PoolLayout lay = pool_layout(P, ring_cap, stack_entries, scene_bytes, cold_bytes, n_rings, word_bytes, stack_entry_bytes, stats_bytes);
+    const PoolLayout lay = pool_layout(P, ring_cap, stack_lds, scene_bytes, cold_bytes, n_rings, word_bytes, stack_entry_bytes, stats_bytes);
     if (lay.total > 160u * 1024u) return hipErrorInvalidValue;
     const int flags = ((tune.stats || fp.counters) ? 1 : 0) | (fp.enable_sunlight ? 2 : 0) | (scene_has_alpha ? 4 : 0) | (hbm_scene ? 8 : 0);
     int threads;
@@ -1197,10 +1236,15 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     // hbm-scene: every step waits for L2, so all the waves a workgroup can have (even a few more lanes than paths: measured on cs16_dust)
     if (hbm_scene && env_threads <= 0) threads = kMaxPoolThreads;
     typedef void (*PoolKernel)(const PoolArgs);
-    static const PoolKernel kernels[16] = { path_pool_kernel<0>, path_pool_kernel<1>, path_pool_kernel<2>, path_pool_kernel<3>,
+    static const PoolKernel kernels[32] = { path_pool_kernel<0>, path_pool_kernel<1>, path_pool_kernel<2>, path_pool_kernel<3>,
                                             path_pool_kernel<4>, path_pool_kernel<5>, path_pool_kernel<6>, path_pool_kernel<7>,
                                             path_pool_kernel<8>, path_pool_kernel<9>, path_pool_kernel<10>, path_pool_kernel<11>,
-                                            path_pool_kernel<12>, path_pool_kernel<13>, path_pool_kernel<14>, path_pool_kernel<15> };
+                                            path_pool_kernel<12>, path_pool_kernel<13>, path_pool_kernel<14>, path_pool_kernel<15>,
+                                            // (deep trees: the stacks' upper levels in HBM)
+                                            path_pool_kernel<32>, path_pool_kernel<33>, path_pool_kernel<34>, path_pool_kernel<35>,
+                                            path_pool_kernel<36>, path_pool_kernel<37>, path_pool_kernel<38>, path_pool_kernel<39>,
+                                            path_pool_kernel<40>, path_pool_kernel<41>, path_pool_kernel<42>, path_pool_kernel<43>,
+                                            path_pool_kernel<44>, path_pool_kernel<45>, path_pool_kernel<46>, path_pool_kernel<47> };
     static const char *const names[16] = { "path_pool<lean,lds-scene>", "path_pool<lean+sun,lds-scene>", "path_pool<lean+alpha,lds-scene>",
                                            "path_pool<lean+alpha+sun,lds-scene>", "path_pool<lean,hbm-scene>", "path_pool<lean+sun,hbm-scene>",
                                            "path_pool<lean+alpha,hbm-scene>", "path_pool<lean+alpha+sun,hbm-scene>",
@@ -1209,7 +1253,8 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
                                            "path_pool<materials+alpha,hbm-scene>", "path_pool<materials+alpha+sun,hbm-scene>" };
     const bool material_model = fp.ext_emissive || fp.ext_specular || fp.ext_transmission;
     // (the material-model variants live in a translation unit of their own, kernel_path_pool_ext.o: no statistics builds of them)
-    const void *const kernel = material_model ? path_pool_ext_kernel(flags & ~1) : reinterpret_cast<const void *>(kernels[flags]);
+    const bool deep = stack_lds < stack_entries;
+    const void *const kernel = material_model ? path_pool_ext_kernel((flags & ~1) | (deep ? 32 : 0)) : reinterpret_cast<const void *>(kernels[flags + (deep ? 16 : 0)]);
     if (lay.total > 64u * 1024u) {
         hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lay.total);
         if (e != hipSuccess) return e;
@@ -1217,7 +1262,7 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lay.total) != hipSuccess || per_cu < 1) per_cu = 1;
     PoolParams pp;
-    pp.P = P; pp.ring_cap = ring_cap; pp.stack_entries = stack_entries;
+    pp.P = P; pp.ring_cap = ring_cap; pp.stack_entries = stack_entries; pp.stack_lds = stack_lds;
     pp.ring_shift = 0;
     while ((1u << pp.ring_shift) < ring_cap) pp.ring_shift++;
     if (P > kMaxPoolPaths || (1u << pp.ring_shift) != ring_cap || ring_cap < P) return hipErrorInvalidValue;   // 12-bit ids, power-of-two rings
@@ -1262,12 +1307,20 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
         if (ea != hipSuccess) return ea;
         scratch.next_slots = slots;
     }
+    if (stack_lds < stack_entries && slots * (stack_entries - stack_lds) > scratch.stack_slots) {
+        if (scratch.aux_stack) (void)hipFree(scratch.aux_stack);
+        scratch.aux_stack = nullptr; scratch.stack_slots = 0;
+        const hipError_t ea = hipMalloc(&scratch.aux_stack, slots * (stack_entries - stack_lds) * 8);
+        if (ea != hipSuccess) return ea;
+        scratch.stack_slots = slots * (stack_entries - stack_lds);
+    }
+    pp.aux_stack = static_cast<uint2 *>(scratch.aux_stack);
     pp.aux = static_cast<uint4 *>(scratch.aux); pp.aux_slot = static_cast<uint32_t *>(scratch.aux_slot);
     pp.aux_light = static_cast<float4 *>(scratch.aux_light);
     pp.aux_next = static_cast<float4 *>(scratch.aux_next);
     hipError_t e = hipSuccess;                 // (sample_counter: kPoolSampleShards zeroed counters, kPoolSampleShardStride words apart -- drt_capi.cpp hands out zeroed blocks)
     if (kernel_name) *kernel_name = names[(flags >> 1) + (material_model ? 8 : 0)];
-    if (launch_shape) { launch_shape[0] = (int)stack_entries; launch_shape[1] = per_cu; launch_shape[2] = (int)(lay.total / 1024); launch_shape[3] = threads; launch_shape[4] = (int)P; }
+    if (launch_shape) { launch_shape[0] = (int)(stack_entries | (stack_lds << 8)); launch_shape[1] = per_cu; launch_shape[2] = (int)(lay.total / 1024); launch_shape[3] = threads; launch_shape[4] = (int)P; }
     FrameParams fq = fp;
     fq.inline_resolve = fp.n_frames == 1 ? 1 : 0;
     PoolArgs args;

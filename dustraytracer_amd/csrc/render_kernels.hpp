@@ -47,8 +47,8 @@ constexpr int kPoolSampleShards = DRT_SAMPLE_SHARDS, kPoolSampleShardStride = 32
 // whose traversal data fits LDS.  `status` is a device word the kernel sets when it had to abort (never hangs).
 bool path_pool_supports(const SceneView &scene, const FrameParams &frame, int bvh_depth, size_t scene_lds_bytes, bool *hbm_scene);
 void path_pool_leaf_classes(const std::vector<LeafRange> &leaves, uint32_t out[3]);
-struct PoolTuning { int threads = 0, paths = 0, min_fill = 48, patience = 8, n_loop = 8, n_min_lanes = 16, n_fuse_loop = 8, n_fuse_min = 24, cold_lds_kb = -1, share_grid = 1, dir_tries = 4; unsigned long long *stats = nullptr; };      // 0 = the launcher's default; stats: device u64[40] (DRT_POOL_STATS=1)
-struct PoolScratch { void *aux = nullptr, *aux_slot = nullptr, *aux_light = nullptr, *aux_next = nullptr; size_t slots = 0, next_slots = 0; };     // HBM part of the path state, owned by the renderer
+struct PoolTuning { int threads = 0, paths = 0, stack_lds = 0, min_fill = 48, patience = 8, n_loop = 8, n_min_lanes = 16, n_fuse_loop = 8, n_fuse_min = 24, cold_lds_kb = -1, share_grid = 1, dir_tries = 4; unsigned long long *stats = nullptr; };      // 0 = the launcher's default; stats: device u64[40] (DRT_POOL_STATS=1)
+struct PoolScratch { void *aux = nullptr, *aux_slot = nullptr, *aux_light = nullptr, *aux_next = nullptr, *aux_stack = nullptr; size_t slots = 0, next_slots = 0, stack_slots = 0; };     // HBM part of the path state, owned by the renderer
 hipError_t launch_path_pool(const SceneView &scene, const FrameParams &frame, int bvh_depth, bool scene_has_alpha, bool hbm_scene, const uint32_t t_class[3], const PoolTuning &tune,
                             PoolScratch &scratch, unsigned int *sample_counter, void *samples, unsigned int *status, int num_cus, hipStream_t stream, const char **kernel_name,
                             int *launch_shape /* out[5]: stack slots, workgroups per CU, LDS KiB, threads, pool paths */);

@@ -4,6 +4,8 @@ Bar (BASELINE.json north_star): per-pixel L-inf < 1e-4 on the RGBA32F framebuffe
 is stricter -- bit-identical floats, because one ulp in the rejection sampler desynchronises a whole
 path -- so every test also reports/limits the number of pixels that are not bit-equal.
 """
+import re
+
 import numpy as np
 import pytest
 
@@ -506,7 +508,7 @@ def test_edge_case_scenes_and_frame_sizes(renderer):
     assert sc.bvh_depth > 16
     img, ref = _render_both(renderer, sc, osc, (0.0, 0.5, 9.0), (0, -0.05, -1), 96, 54, 2, ray_bounce_limit=6)
     compare(img, ref, "soup depth %d" % sc.bvh_depth)
-    assert renderer.kernelInfo().startswith("path_pool<lean+alpha,hbm-scene>") and "stack=%d " % (sc.bvh_depth - 1) in renderer.kernelInfo(), renderer.kernelInfo()
+    assert renderer.kernelInfo().startswith("path_pool<lean+alpha,hbm-scene>") and re.search(r"stack=%d[ (]" % (sc.bvh_depth - 1), renderer.kernelInfo()), renderer.kernelInfo()
     img, ref = _render_both(renderer, sc, osc, (0.0, 0.5, 9.0), (0, -0.05, -1), 96, 54, 2, ray_bounce_limit=6, enableSunlight=1)
     compare(img, ref, "soup with sun shadows through cut-outs")
     # (2b) a small scene under a degenerate tree: 62 triangles whose centroids double in x peel off one per level (leaf size 1, two
@@ -523,7 +525,9 @@ def test_edge_case_scenes_and_frame_sizes(renderer):
         img, ref = _render_both(renderer, sc, osc, (-3.0, 0.1, 0.2), (1.0, 0.02, -0.03), 64, 36, 2, ray_bounce_limit=3, **kw)
         compare(img, ref, "degenerate %d-level tree %r (%s)" % (sc.bvh_depth, kw, renderer.kernelInfo()))
         # (path_pool keeps the near child of a visit in registers: one stack slot per level below the root)
-        assert "stack=%d " % (sc.bvh_depth - 1 if renderer.kernelInfo().startswith("path_pool") else sc.bvh_depth) in renderer.kernelInfo()
+        assert re.search(r"stack=%d[ (]" % (sc.bvh_depth - 1 if renderer.kernelInfo().startswith("path_pool") else sc.bvh_depth), renderer.kernelInfo())
+        if renderer.kernelInfo().startswith("path_pool"):
+            assert " in LDS)" in renderer.kernelInfo(), renderer.kernelInfo()      # (a tree this deep: most stack levels live in HBM)
     # (3) long paths: the closed cornell box with 32 bounces
     sc, osc = make_pair("cornell_box")
     cam, ocam = cameras("cornell_box")
@@ -609,8 +613,8 @@ def test_kernel_packaging_is_measured_not_guessed():
     shape follows from what fits LDS).  Checked: the image is the oracle's whatever is being tried, every candidate gets its trials,
     and the one kept is the best measured (within 2 %)."""
     expect = {"cornell_box": "path_pool<lean,lds-scene> stack=2 wg/CU=2 ",             # small LDS scene, lean paths: the path pool, two pools per CU
-              "room": "path_pool<lean,lds-scene> stack=7 wg/CU=1 ",                    # 17.6 KB LDS scene, 8-level tree: one pool per CU
-              "cs16_dust": "path_pool<lean,hbm-scene> stack=15 wg/CU=1 threads=1024 ",  # tree read from global memory: 6-byte stack entries, one pool per CU
+              "room": "path_pool<lean,lds-scene> stack=7(6 in LDS) wg/CU=1 ",          # 17.6 KB LDS scene, 8-level tree: one pool per CU, the stacks' top level in HBM
+              "cs16_dust": "path_pool<lean,hbm-scene> stack=15(8 in LDS) wg/CU=1 threads=1024 ",  # tree read from global memory: 6-byte stack entries, one pool per CU
               "suzanne_plane": "path_pool<lean,hbm-scene> stack=9 wg/CU=1 threads=1024 "}
     r = drt.Renderer(0)
     r_wq = _renderer_with_env({"DRT_KERNEL": "wave_queue"})
@@ -677,6 +681,20 @@ def test_path_pool_scheduling_knobs_do_not_change_the_image(env):
     r, ref, _ = _render_with_env(dict(env, DRT_KERNEL="path_pool"), "room", 96, 54, 2, 6)
     assert r.kernelInfo().startswith("path_pool"), r.kernelInfo()
     compare(r.GetRenderTargetImage(), ref, "pool knobs %r" % (env,))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("levels", ["1", "2", "4"])
+@pytest.mark.parametrize("name,W,H,frames,depth,sun", [("room", 96, 54, 2, 8, 0), ("room", 96, 54, 2, 6, 1), ("cs16_dust", 96, 54, 2, 4, 0), ("cs16_dust", 96, 54, 2, 4, 1),
+                                                        ("dense_monkey", 96, 54, 2, 3, 0), ("mc_transparency", 96, 54, 2, 4, 1), ("suzanne_plane", 96, 54, 2, 2, 0)])
+def test_stack_levels_in_hbm_do_not_change_the_image(levels, name, W, H, frames, depth, sun):
+    """Deep trees: path_pool keeps only the bottom levels of the traversal stacks in LDS and the rest in HBM (chosen by the launcher;
+    forced here to 1, 2 and 4 levels so that nearly every push and pop of these scenes goes through the HBM part): where a stack
+    entry lives is not arithmetic -- the oracle's bits, closest-hit and shadow traversals, scene in LDS and read from global memory."""
+    r, ref, ref_acc = _render_with_env({"DRT_KERNEL": "path_pool", "DRT_POOL_STACK_LDS": levels}, name, W, H, frames, depth, enableSunlight=sun)
+    assert r.kernelInfo().startswith("path_pool") and "(%s in LDS)" % levels in r.kernelInfo(), r.kernelInfo()
+    compare(r.GetRenderTargetImage(), ref, "%s, %s stack levels in LDS, sun=%d" % (name, levels, sun))
+    compare(r.GetAccumulationBuffer(), ref_acc, "%s accum" % name)
 
 
 @pytest.mark.gpu

@@ -29,7 +29,7 @@ def pretty(name):
     m = re.search(r"path_pool_kernelILi(\d+)E", name)
     if m:
         f = int(m.group(1))
-        what = VARIANT[f & 6].replace("lean", "materials" if f & 16 else "lean") + (", hbm-scene" if f & 8 else ", lds-scene") + (", statistics build" if f & 1 else "")
+        what = VARIANT[f & 6].replace("lean", "materials" if f & 16 else "lean") + (", hbm-scene" if f & 8 else ", lds-scene") + (", deep stacks" if f & 32 else "") + (", statistics build" if f & 1 else "")
         return "path_pool<%d> (%s)" % (f, what)
     m = re.search(r"\d+(\w+_kernel)", name)
     return m.group(1) if m else name
