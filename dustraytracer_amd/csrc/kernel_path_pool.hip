@@ -1173,68 +1173,69 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     // mod P by multiplication -- were tried too: room's pool grows from 1216 to 1344 paths, and the extra arithmetic in every claim
     // and push costs the 3 % that buys.)
     const uint32_t stack_entries = (uint32_t)std::max(bvh_depth - 1, 1);
-    // The levels of the stacks kept in LDS (tune.stack_lds; 0 = chosen below): all of them, unless the tree is so deep that its
-    // stacks leave one workgroup of 1024 threads fewer than ~1.3 paths per lane -- the pool then runs short of full batches.
-    // In that case only the stacks' bottom levels stay in LDS and the rest goes to HBM (path_pool_kernel<FLAGS | 32>): the
-    // entries a path pushes when it is deep in the tree are few, and the paths the freed LDS holds are worth more.  Measured
-    // (tools/experiments/r03/sweep_stack_lds.sh; levels in LDS -> paths -> Msamples/s): dense_monkey, 14 levels: all 1024 -> 9 513,
-    // 8 -> 1 344 -> 10 593, 6 -> 1 536 -> 10 503; cs16_dust, 15 levels: all -> 1 024 -> 1 094, 7 -> 1 408 -> 1 235; room 4K, 7 levels: all ->
-    // 1 216 -> 847, 5 -> 1 472 -> 864, 3 -> 1 856 -> 862: beyond ~1 350 paths per 1 024 threads more paths buy nothing.
+    // The levels of the stacks kept in LDS (tune.stack_lds; 0 = chosen below, with the pool's shape)
     uint32_t stack_lds = tune.stack_lds > 0 ? std::min<uint32_t>((uint32_t)tune.stack_lds, stack_entries) : stack_entries;
     const uint32_t scene_bytes = hbm_scene ? 0u : pool_scene_bytes(sc);
     const uint32_t word_bytes = hbm_scene ? 16u : 4u, stack_entry_bytes = hbm_scene ? 6u : 8u;
     // the shading records go to LDS too when they are small (cornell: 1.2 KB): B's load chain triangle -> material ->
     // texture header then runs through LDS instead of three dependent HBM / L2 round trips
     uint32_t cold_bytes = pool_cold_bytes(sc) <= (tune.cold_lds_kb >= 0 ? (uint32_t)tune.cold_lds_kb * 1024u : 4096u) ? pool_cold_bytes(sc) : 0u;
-    // Workgroups per CU, pool size and threads: the most paths the CU's 160 KB of LDS hold (rings are sized to the next power of
-    // two, so 1024 paths per workgroup is a sweet spot), then as many threads as paths, at most 24 waves per CU (16 in one workgroup).
+    // Workgroups per CU, paths per pool, threads, stack levels in LDS.  Two things keep a CU busy: resident waves (at most 24 here:
+    // 6 per SIMD at this kernel's 106 SGPRs; 16 in one workgroup) and ~1.3 paths per lane, so that a wave finds a full batch
+    // when it looks for one (768 -> 1024 paths at 768 threads: -13 % time; beyond ~1.35 per lane more paths buy nothing).  What
+    // stands in the way is LDS: rings are sized to the next power of two (1024 paths per workgroup is a sweet spot), and every
+    // stack level costs 8 (6) bytes per path.  A deep tree therefore keeps only the BOTTOM k levels of its stacks in LDS and the
+    // rest in HBM (path_pool_kernel<FLAGS | 32>): a path is deep in the tree on few of its visits, and what the freed LDS holds
+    // is worth more -- paths (dense_monkey, 14 levels: all in LDS 1024 paths, 9 513 Msamples/s; 8 levels 1344 paths, 10 593;
+    // cs16_dust 1 094 -> 1 231) or a second workgroup (room 4K, 7 levels, scene copy in LDS: 1 x 1216 paths x 16 waves 847 Msamples/s;
+    // 6 levels, 1 x 1344 x 16 waves 860; ONE level, 2 x 1024 x 12 waves 1 000).  Every shape is scored by the lanes it can keep
+    // busy, min(resident lanes, paths / 1.25); ties go to more levels in LDS, then to fewer workgroups.
+    // (tools/experiments/r03/sweep_stack_lds.sh, room_two_pools.sh)
     const uint32_t n_rings = fp.enable_sunlight ? (uint32_t)kNQ : (uint32_t)kNQ - 1u;
     const uint32_t stats_bytes = (tune.stats || fp.counters) ? kStatsBytes : 0u;         // (the statistics build keeps its per-queue sums in LDS)
-    auto lds_for = [&](uint32_t paths, uint32_t &cap) {
+    auto lds_for = [&](uint32_t paths, uint32_t &cap, uint32_t levels) {
         cap = 64;
         while (cap < paths) cap *= 2;
-        return pool_layout(paths, cap, stack_lds, scene_bytes, cold_bytes, n_rings, word_bytes, stack_entry_bytes, stats_bytes).total;
+        return pool_layout(paths, cap, levels, scene_bytes, cold_bytes, n_rings, word_bytes, stack_entry_bytes, stats_bytes).total;
+    };
+    auto threads_for = [&](uint32_t paths, int g) {
+        // hbm-scene: every step waits for L2, so all the waves a workgroup can have (even a few more lanes than paths: measured on cs16_dust)
+        if (hbm_scene) return kMaxPoolThreads;
+        return std::max(256, std::min<int>({ kMaxPoolThreads, (int)paths / 64 * 64, 1536 / g / 64 * 64 }));
     };
     uint32_t P = 0, ring_cap = 64;
     int groups = 1;
     if (env_paths > 0) {
         P = std::max<uint32_t>(64u, std::min<uint32_t>((uint32_t)env_paths / 64u * 64u, kMaxPoolPaths));
-        while (P > 64u && lds_for(P, ring_cap) > 160u * 1024u) P -= 64u;
-        (void)lds_for(P, ring_cap);
+        while (P > 64u && lds_for(P, ring_cap, stack_lds) > 160u * 1024u) P -= 64u;
     } else {
-        // (hbm-scene: one pool per CU -- what counts there is resident waves AND spare paths, and one big pool has both)
-        auto best_pool = [&]() {
-            uint32_t best_total = 0;
-            for (int g = 1; g <= (hbm_scene ? 1 : 3); g++)
-                for (uint32_t paths = kMaxPoolPaths; paths >= 256u; paths -= 64u) {
-                    uint32_t cap;
-                    if (lds_for(paths, cap) * (uint32_t)g > 160u * 1024u) continue;
-                    if (paths * (uint32_t)g >= best_total) { best_total = paths * (uint32_t)g; P = paths; groups = g; }
-                    break;
-                }
+        // (hbm-scene: one pool per CU -- two workgroups of 10 waves do not fit the SIMDs side by side, and 12 would need 80 VGPRs)
+        auto best_shape = [&]() {
+            uint32_t best_score = 0, best_levels = stack_lds;
+            const uint32_t k_first = stack_lds, k_last = tune.stack_lds > 0 ? stack_lds : 1u;
+            for (uint32_t k = k_first; k >= k_last; --k)
+                for (int g = 1; g <= (hbm_scene ? 1 : 3); g++)
+                    for (uint32_t paths = kMaxPoolPaths; paths >= 256u; paths -= 64u) {
+                        uint32_t cap;
+                        if (lds_for(paths, cap, k) * (uint32_t)g > 160u * 1024u) continue;
+                        const uint32_t lanes = std::min<uint32_t>(1536u, (uint32_t)g * (uint32_t)threads_for(paths, g));
+                        const uint32_t score = std::min<uint32_t>(lanes, paths * (uint32_t)g * 4u / 5u);
+                        if (score > best_score) { best_score = score; P = paths; groups = g; best_levels = k; }
+                        break;
+                    }
+            stack_lds = best_levels;
         };
-        best_pool();
+        best_shape();
         // path_pool_supports sizes its smallest pool without the staged shading records: a small scene under a very deep tree may
         // leave no room for them -- the records then stay in global memory rather than the launch failing
-        if (P == 0 && cold_bytes > 0) { cold_bytes = 0; best_pool(); }
+        if (P == 0 && cold_bytes > 0) { cold_bytes = 0; best_shape(); }
         if (P == 0) return hipErrorInvalidValue;
-        if (tune.stack_lds == 0 && groups == 1 && P < 1280u && stack_entries > 2u) {
-            // deep tree: the most levels in LDS that still leave room for 1344 paths (or, failing that, two levels)
-            for (stack_lds = stack_entries - 1u; ; --stack_lds) {
-                best_pool();
-                if (P * (uint32_t)groups >= 1344u || stack_lds == 2u) break;
-            }
-        }
-        (void)lds_for(P, ring_cap);
     }
+    (void)lds_for(P, ring_cap, stack_lds);
     const PoolLayout lay = pool_layout(P, ring_cap, stack_lds, scene_bytes, cold_bytes, n_rings, word_bytes, stack_entry_bytes, stats_bytes);
     if (lay.total > 160u * 1024u) return hipErrorInvalidValue;
     const int flags = ((tune.stats || fp.counters) ? 1 : 0) | (fp.enable_sunlight ? 2 : 0) | (scene_has_alpha ? 4 : 0) | (hbm_scene ? 8 : 0);
-    int threads;
-    if (env_threads > 0) threads = std::max(64, std::min(env_threads, kMaxPoolThreads) / 64 * 64);
-    else threads = std::max(256, std::min<int>({ kMaxPoolThreads, (int)P / 64 * 64, 1536 / groups / 64 * 64 }));
-    // hbm-scene: every step waits for L2, so all the waves a workgroup can have (even a few more lanes than paths: measured on cs16_dust)
-    if (hbm_scene && env_threads <= 0) threads = kMaxPoolThreads;
+    const int threads = env_threads > 0 ? std::max(64, std::min(env_threads, kMaxPoolThreads) / 64 * 64) : threads_for(P, groups);
     typedef void (*PoolKernel)(const PoolArgs);
     static const PoolKernel kernels[32] = { path_pool_kernel<0>, path_pool_kernel<1>, path_pool_kernel<2>, path_pool_kernel<3>,
                                             path_pool_kernel<4>, path_pool_kernel<5>, path_pool_kernel<6>, path_pool_kernel<7>,
