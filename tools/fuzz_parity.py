@@ -30,9 +30,22 @@ def get(name):
     return loaded[name]
 
 
-r = drt.Renderer(0)
+def renderer_with(env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return drt.Renderer(0)                  # the knobs are read when the renderer is created
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+
+
+# the launcher's own choice of how many stack levels stay in LDS, and 1 / 3 levels forced (deep trees: the rest of a stack lives in HBM)
+renderers = [drt.Renderer(0), renderer_with({"DRT_POOL_STACK_LDS": "1"}), renderer_with({"DRT_POOL_STACK_LDS": "3"})]
 bad, kernels, t0 = 0, {}, time.time()
 for case in range(n_cases):
+    r = renderers[0 if rng.integers(2) == 0 else int(rng.integers(1, 3))]
     name = names[rng.integers(len(names))]
     sc, osc, lo, hi = get(name)
     ext = hi - lo
@@ -79,7 +92,8 @@ for case in range(n_cases):
     img = r.GetRenderTargetImage()
     ref, _, _ = oracle.render(osc, ocam, oracle.default_settings(**{oname.get(k, k): v for k, v in st.items()}), W, H, 1, frames, threads=8)
     osc.material_model = (0, 0, 1.0, 0)
-    kernels[r.kernelInfo().split()[0]] = kernels.get(r.kernelInfo().split()[0], 0) + 1
+    kname = r.kernelInfo().split()[0] + (" deep stacks" if " in LDS)" in r.kernelInfo() else "")
+    kernels[kname] = kernels.get(kname, 0) + 1
     a, b = img.view(np.uint32), ref.view(np.uint32)
     both_nan = np.isnan(img) & np.isnan(ref)
     nbad = int(((a != b) & ~both_nan).any(axis=-1).sum())

@@ -36,6 +36,6 @@ for name, W, H, spp, depth, kw in CASES:
     nbad = int((img.view(np.uint32) != ref.view(np.uint32)).any(axis=-1).sum())
     bad_total += nbad
     print("%-16s %dx%d x%d spp depth %d %s: %s  GPU %.1f ms (%.0f Msamples/s), oracle %.1f s, pixels not bit-equal: %d"
-          % (name, W, H, spp, depth, kw, r.kernelInfo().split()[0], ms, W * H * spp / ms / 1e3, dt, nbad), flush=True)
+          % (name, W, H, spp, depth, kw, r.kernelInfo(), ms, W * H * spp / ms / 1e3, dt, nbad), flush=True)
 print("TOTAL pixels not bit-equal:", bad_total)
 sys.exit(1 if bad_total else 0)
