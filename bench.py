@@ -9,7 +9,7 @@ A "step" is one full progressive render of the frame: reset the accumulation buf
 of the workload (W x H x spp paths: ray generation, BVH traversal, shading, accumulate, resolve) and,
 for N > 1, gather the rank-local framebuffer stripes on rank 0 over RCCL and assemble the image.
 Inputs (scene, BVH, textures) are resident in HBM before the timed region.  One JSON line on rank 0.
-Steps are independent frames; --frames-in-flight (default 4; 2 for the one-second steps of room 4K) of them are enqueued at a time, each on its own
+Steps are independent frames; --frames-in-flight (default 4; 1 for the half-second steps of room 4K) of them are enqueued at a time, each on its own
 renderer + HIP stream, so the end-of-launch drain of one frame and its gather overlap the next frame's
 ramp-up.  Every step still does all of its work inside the timed region (drained before the closing sync).
 
@@ -211,10 +211,11 @@ def main_group(args):
 def main():
     args = parse_args()
     if args.frames_in_flight <= 0:
-        # 4 (on the 8 hardware queues asked for above); 2 for the one-second steps of room 4K.  Launches of a millisecond or less are
+        # 4 (on the 8 hardware queues asked for above); 1 for the half-second steps of room 4K.  Launches of a millisecond or less are
         # mostly ramp-up and drain, and each one more in flight hides more of that: 256^2 x 1 spp 0.083 -> 0.065 ms, the 1/8 shard
         # 0.40 -> 0.37, suzanne 1.46 -> 1.40; cornell 1080p x 8 spp is the same with 3 and 4 (2.59 ms), 6 is worse everywhere.
-        args.frames_in_flight = 2 if args.workload == "room_4k_64spp_d16" else 4
+        # (room 4K, half a second per launch on full grids: one at a time -- 1 015 Msamples/s with 1 or 2 in flight over four steps, 785 with 3)
+        args.frames_in_flight = 1 if args.workload == "room_4k_64spp_d16" else 4
     if args.group:
         return main_group(args)
     rank = int(os.environ.get("RANK", "0"))

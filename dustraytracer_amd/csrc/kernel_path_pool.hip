@@ -1189,7 +1189,9 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     // is worth more -- paths (dense_monkey, 14 levels: all in LDS 1024 paths, 9 513 Msamples/s; 8 levels 1344 paths, 10 593;
     // cs16_dust 1 094 -> 1 231) or a second workgroup (room 4K, 7 levels, scene copy in LDS: 1 x 1216 paths x 16 waves 847 Msamples/s;
     // 6 levels, 1 x 1344 x 16 waves 860; ONE level, 2 x 1024 x 12 waves 1 000).  Every shape is scored by the lanes it can keep
-    // busy, min(resident lanes, paths / 1.25); ties go to more levels in LDS, then to fewer workgroups.
+    // busy, min(resident lanes, paths / 1.19); ties go to more levels in LDS, then to fewer workgroups.  (1.19, not 1.3: a pool of
+    // 1216 paths per 1024 threads gains nothing from stack levels in HBM -- suzanne with sunlight, whose shadow traversals push more
+    // entries: 2.56 ms with all 9 levels in LDS, 2.66 with 8 and 1280 paths.)
     // (tools/experiments/r03/sweep_stack_lds.sh, room_two_pools.sh)
     const uint32_t n_rings = fp.enable_sunlight ? (uint32_t)kNQ : (uint32_t)kNQ - 1u;
     const uint32_t stats_bytes = (tune.stats || fp.counters) ? kStatsBytes : 0u;         // (the statistics build keeps its per-queue sums in LDS)
@@ -1219,7 +1221,7 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
                         uint32_t cap;
                         if (lds_for(paths, cap, k) * (uint32_t)g > 160u * 1024u) continue;
                         const uint32_t lanes = std::min<uint32_t>(1536u, (uint32_t)g * (uint32_t)threads_for(paths, g));
-                        const uint32_t score = std::min<uint32_t>(lanes, paths * (uint32_t)g * 4u / 5u);
+                        const uint32_t score = std::min<uint32_t>(lanes, paths * (uint32_t)g * 16u / 19u);
                         if (score > best_score) { best_score = score; P = paths; groups = g; best_levels = k; }
                         break;
                     }

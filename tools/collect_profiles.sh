@@ -42,7 +42,7 @@ cp $O/${TAG}_roofline_*.json $R/profiles/ 2>/dev/null || true
 cd $R
 python3 bench.py > $O/${TAG}_bench_default.json
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_f3 -o f3 -- python3 $R/bench.py --cpu-seconds 0 > $O/${TAG}_bench_default_under_rocprof.json 2> /tmp/p_f3.log; cp /tmp/p_f3/f3_kernel_stats.csv $O/${TAG}_bench_default_kernel_stats.csv)
-python3 bench.py --workload room_4k_64spp_d16 --cpu-seconds 10 --steps 3 --warmup 1 > $O/${TAG}_bench_room_4k_64spp_d16.json
+python3 bench.py --workload room_4k_64spp_d16 --cpu-seconds 10 --steps 4 --warmup 1 > $O/${TAG}_bench_room_4k_64spp_d16.json
 for wl in suzanne_plane_1080p_8spp_d2 dense_monkey_1080p_16spp_d2 cs16_dust_1080p_8spp_d5 cornell_box_256_1spp_d4 mc_transparency_843x460_50spp_d5; do
   python3 bench.py --workload $wl --cpu-seconds 3 > $O/${TAG}_bench_$wl.json
 done
