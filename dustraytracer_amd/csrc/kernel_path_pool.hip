@@ -185,7 +185,9 @@ struct PoolParams {
 // FLAGS: 1 = statistics, 2 = sunlight (a shadow ray per shaded hit, RayGen.cuh:124-128), 4 = alpha cut-outs (AnyHit.cuh:8-28),
 // 8 = hbm-scene: the traversal data is too big for LDS and is read from global memory (L2); the pool -- path state, stacks, queues --
 // is the same, with 32-bit triangle indices: word W becomes a quad {meta = bounce | stack height << 16 | flags, hit triangle, leaf end, -}
-// and B's fourth word the current triangle
+// and B's fourth word the current triangle; 16 = the opt-in material model (kernel_path_pool_ext.o);
+// 32 = deep tree: only the bottom PoolParams::stack_lds levels of the traversal stacks are in LDS, the levels above them in HBM
+// (launch_path_pool chooses: the LDS that frees holds more paths, or a second workgroup per CU)
 // The arguments travel as ONE struct, and the kernel never names it: every field is read from the kernarg segment where it is
 // used, through a pointer that is made opaque at the top of every batch (`ka`, below).  Named by-value arguments are loaded at
 // the kernel's entry and stay live across the whole loop -- ~130 dwords of them, which the register allocator then spills to
