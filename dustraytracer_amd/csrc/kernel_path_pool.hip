@@ -66,6 +66,16 @@ constexpr uint32_t kBackFace = 1u << 30;             // the shaded hit was seen 
 constexpr uint32_t kOccluded = 1u << 31;             // the shadow ray hit something
 constexpr uint32_t kMetal = 1u << 27;                // material-model builds: the direction being drawn is the mirror lobe's (R finds roughness and normal again from the hit triangle)
 constexpr int kMaxPoolThreads = 1024;                // up to 16 waves per workgroup = 4 per SIMD (128 VGPRs each)
+// The hbm-scene production kernels are built NARROW: at most 12 waves per workgroup and 80 VGPRs (6 waves per SIMD), two triangles per
+// T step instead of four -- so that TWO workgroups are resident per CU, 24 waves instead of 16.  Those builds wait for L2 ~43 % of
+// their cycles; half as many loads in flight per lane and half as many more waves is the better trade: dense_monkey 10 519 -> 11 800
+// Msamples/s, suzanne 11 750 -> 13 000, cs16_dust 1 230 -> 1 310 (tools/experiments/r03/patches/hbm_two_pools.patch is the experiment).
+// Held to 80 VGPRs WITH four triangles per step the same kernel spills 25 of them and loses 7-14 %.  (A workgroup's waves must divide by
+// four: two workgroups of 10 waves -- 96 VGPRs -- do not fit side by side, 3 + 3 + 2 + 2 on the SIMDs twice.)  The statistics builds
+// carry eleven more counters per lane and stay wide: one workgroup of 16 waves.
+constexpr bool pool_narrow(int flags) { return (flags & 8) != 0 && (flags & 1) == 0; }
+constexpr int pool_max_threads(int flags) { return pool_narrow(flags) ? 768 : kMaxPoolThreads; }
+constexpr int pool_min_waves(int flags) { return pool_narrow(flags) ? 6 : 4; }
 
 typedef uint32_t pp_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t pp_u32x2 __attribute__((ext_vector_type(2)));
@@ -195,7 +205,7 @@ struct PoolParams {
 // camera, sky and frame constants occupy registers only inside the phase that needs them.
 struct PoolArgs { SceneView sc; FrameParams fp; PoolParams pp; unsigned int *sample_counter; float4 *samples; };
 template <int FLAGS>
-__global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolArgs) {
+__global__ __launch_bounds__(pool_max_threads(FLAGS)) __attribute__((amdgpu_waves_per_eu(pool_min_waves(FLAGS)))) void path_pool_kernel(const PoolArgs) {
     // the kernel arguments, read from the kernarg segment (scalar loads) at the point of use
     typedef const PoolArgs __attribute__((address_space(4))) *KernArgs;
     KernArgs ka = (KernArgs)__builtin_amdgcn_kernarg_segment_ptr();
@@ -730,11 +740,11 @@ __global__ __launch_bounds__(kMaxPoolThreads) void path_pool_kernel(const PoolAr
                 if (SUN) shadow = (meta & kShadow) != 0;
             }
             const float hit_t_in = hit_t;
-            // hbm-scene: four triangles per step -- four loads in flight per lane instead of two (the step waits for memory, not for
-            // the arithmetic); tested and applied in the leaf's order
+            // hbm-scene: four triangles per step in the wide build -- four loads in flight per lane instead of two (the step waits for
+            // memory, not for the arithmetic) --, two in the narrow one (pool_narrow); tested and applied in the leaf's order
             while (HBM && pp_ballot(cur < end) != 0) {
                 if (cur < end) {
-                    constexpr int kWide = 4;
+                    constexpr int kWide = pool_narrow(FLAGS) ? 2 : 4;
                     int idx[kWide];
                     TriTest tri[kWide];
 #pragma unroll
@@ -1202,10 +1212,12 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
         while (cap < paths) cap *= 2;
         return pool_layout(paths, cap, levels, scene_bytes, cold_bytes, n_rings, word_bytes, stack_entry_bytes, stats_bytes).total;
     };
+    const int flags = ((tune.stats || fp.counters) ? 1 : 0) | (fp.enable_sunlight ? 2 : 0) | (scene_has_alpha ? 4 : 0) | (hbm_scene ? 8 : 0);
+    const int max_threads = pool_max_threads(flags);
     auto threads_for = [&](uint32_t paths, int g) {
         // hbm-scene: every step waits for L2, so all the waves a workgroup can have (even a few more lanes than paths: measured on cs16_dust)
-        if (hbm_scene) return kMaxPoolThreads;
-        return std::max(256, std::min<int>({ kMaxPoolThreads, (int)paths / 64 * 64, 1536 / g / 64 * 64 }));
+        if (hbm_scene) return std::min(max_threads, 1536 / g / 64 * 64);
+        return std::max(256, std::min<int>({ max_threads, (int)paths / 64 * 64, 1536 / g / 64 * 64 }));
     };
     uint32_t P = 0, ring_cap = 64;
     int groups = 1;
@@ -1213,12 +1225,12 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
         P = std::max<uint32_t>(64u, std::min<uint32_t>((uint32_t)env_paths / 64u * 64u, kMaxPoolPaths));
         while (P > 64u && lds_for(P, ring_cap, stack_lds) > 160u * 1024u) P -= 64u;
     } else {
-        // (hbm-scene: one pool per CU -- two workgroups of 10 waves do not fit the SIMDs side by side, and 12 would need 80 VGPRs)
+        // (hbm-scene: two pools of 12 waves per CU with the narrow kernels, one of 16 with the wide statistics builds)
         auto best_shape = [&]() {
             uint32_t best_score = 0, best_levels = stack_lds;
             const uint32_t k_first = stack_lds, k_last = tune.stack_lds > 0 ? stack_lds : 1u;
             for (uint32_t k = k_first; k >= k_last; --k)
-                for (int g = 1; g <= (hbm_scene ? 1 : 3); g++)
+                for (int g = 1; g <= (hbm_scene ? (pool_narrow(flags) ? 2 : 1) : 3); g++)
                     for (uint32_t paths = kMaxPoolPaths; paths >= 256u; paths -= 64u) {
                         uint32_t cap;
                         if (lds_for(paths, cap, k) * (uint32_t)g > 160u * 1024u) continue;
@@ -1238,8 +1250,7 @@ hipError_t launch_path_pool(const SceneView &sc, const FrameParams &fp, int bvh_
     (void)lds_for(P, ring_cap, stack_lds);
     const PoolLayout lay = pool_layout(P, ring_cap, stack_lds, scene_bytes, cold_bytes, n_rings, word_bytes, stack_entry_bytes, stats_bytes);
     if (lay.total > 160u * 1024u) return hipErrorInvalidValue;
-    const int flags = ((tune.stats || fp.counters) ? 1 : 0) | (fp.enable_sunlight ? 2 : 0) | (scene_has_alpha ? 4 : 0) | (hbm_scene ? 8 : 0);
-    const int threads = env_threads > 0 ? std::max(64, std::min(env_threads, kMaxPoolThreads) / 64 * 64) : threads_for(P, groups);
+    const int threads = env_threads > 0 ? std::max(64, std::min(env_threads, max_threads) / 64 * 64) : threads_for(P, groups);
     typedef void (*PoolKernel)(const PoolArgs);
     static const PoolKernel kernels[32] = { path_pool_kernel<0>, path_pool_kernel<1>, path_pool_kernel<2>, path_pool_kernel<3>,
                                             path_pool_kernel<4>, path_pool_kernel<5>, path_pool_kernel<6>, path_pool_kernel<7>,

@@ -614,8 +614,9 @@ def test_kernel_packaging_is_measured_not_guessed():
     and the one kept is the best measured (within 2 %)."""
     expect = {"cornell_box": "path_pool<lean,lds-scene> stack=2 wg/CU=2 ",             # small LDS scene, lean paths: the path pool, two pools per CU
               "room": "path_pool<lean,lds-scene> stack=7(1 in LDS) wg/CU=2 threads=768 paths=1024 ",   # 17.6 KB LDS scene, 8-level tree: two pools per CU, all but one stack level in HBM
-              "cs16_dust": "path_pool<lean,hbm-scene> stack=15(9 in LDS) wg/CU=1 threads=1024 paths=1280 ",  # tree read from global memory: 6-byte stack entries, one pool per CU, the stacks' upper levels in HBM
-              "suzanne_plane": "path_pool<lean,hbm-scene> stack=9 wg/CU=1 threads=1024 "}
+              # trees read from global memory: the narrow kernels (80 VGPRs, two triangles per T step), two pools of 12 waves per CU, 6-byte stack entries of which three levels in LDS
+              "cs16_dust": "path_pool<lean,hbm-scene> stack=15(3 in LDS) wg/CU=2 threads=768 paths=960 ",
+              "suzanne_plane": "path_pool<lean,hbm-scene> stack=9(3 in LDS) wg/CU=2 threads=768 paths=960 "}
     r = drt.Renderer(0)
     r_wq = _renderer_with_env({"DRT_KERNEL": "wave_queue"})
     W, H = 160, 90
